@@ -1,0 +1,32 @@
+# Top-level build: host front-end (g++), CPU oracle (gcc, test infrastructure only), device library (hipcc, gfx950).
+PKG      := navierstokes_project_nm4pde_amd
+CXX      ?= g++
+CC       ?= gcc
+HIPCC    ?= /opt/rocm/bin/hipcc
+CXXFLAGS := -O2 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter
+CFLAGS   := -O3 -march=x86-64-v3 -std=c99 -fPIC -Wall -Wextra -ffp-contract=off
+HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -Wall -Wno-unused-parameter
+
+HOST_SO   := $(PKG)/host/libnsx_host.so
+DEV_SO    := $(PKG)/csrc/libnsx.so
+ORACLE_SO := oracle/liboracle.so
+
+all: host oracle device
+host: $(HOST_SO)
+oracle: $(ORACLE_SO)
+device: $(DEV_SO)
+
+$(HOST_SO): $(PKG)/host/frontend.cpp $(PKG)/host/graph.hpp include/nsx_host.h
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(PKG)/host/frontend.cpp
+
+$(ORACLE_SO): oracle/nsx_oracle.c oracle/nsx_oracle.h
+	$(CC) $(CFLAGS) -shared -o $@ oracle/nsx_oracle.c -lm
+
+DEV_SRC := $(wildcard $(PKG)/csrc/*.hip)
+DEV_HDR := $(wildcard $(PKG)/csrc/*.hpp) include/nsx.h $(PKG)/host/graph.hpp
+$(DEV_SO): $(DEV_SRC) $(DEV_HDR)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(DEV_SRC) -L/opt/rocm/lib -lrccl
+
+clean:
+	rm -f $(HOST_SO) $(DEV_SO) $(ORACLE_SO)
+.PHONY: all host oracle device clean

@@ -1,0 +1,118 @@
+/* nsx_host.h — C API of the host-side front-end (mesh, DoF handler, FE tables).
+ *
+ * This is the CPU "setup" stage that the reference performs with deal.II in
+ * NavierStokes::setup() (reference Navier-Stokes/src/NavierStokes3D.cpp:2-157):
+ * mesh creation + partition (:5-23), FE/quadrature (:27-54), DoF distribution +
+ * block renumbering (:58-93) and sparsity (:97-156).  Its outputs are exactly
+ * the inputs of the device library (include/nsx.h).  No GPU code here.
+ *
+ * All arrays returned by nsxh_* accessors are owned by the object they were
+ * obtained from and stay valid until that object is freed.
+ */
+#ifndef NSX_HOST_H
+#define NSX_HOST_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nsxh_mesh nsxh_mesh;
+typedef struct nsxh_dofs nsxh_dofs;
+typedef struct nsxh_tables nsxh_tables;
+
+/* ---- meshes (reference mesh/ .geo geometries; gmsh is replaced by a block-structured generator) ---- */
+
+/* Channel with a circular obstacle.
+ * dim=2: reference mesh/Cylinder2D.geo:6-22 (2.2 x 0.41, circle c=(0.2,0.2) r=0.05);
+ * dim=3: reference mesh/Cylinder3D.geo:9-15 (2.5 x 0.41 x 0.41, axis z through (0.5,0.2), R=0.05).
+ * Boundary ids as in the .geo files: 0 inlet (x=0), 1 outlet (x=L), 2 walls, 3 obstacle.
+ * `m`  = cells per side of the square that carries the O-grid around the cylinder (even, >=2),
+ * `nr` = radial layers of the O-grid, `nxu`/`nxd` = cells upstream/downstream of the square,
+ * `nyb`/`nyt` = cells below/above the square, `nz` = layers in z (3D only).
+ * `grade_x` >= 1 stretches the downstream cells geometrically, `grade_r` >= 1 the radial layers. */
+nsxh_mesh *nsxh_mesh_cylinder(int dim, int m, int nr, int nxu, int nxd, int nyb, int nyt, int nz,
+                              double grade_x, double grade_r);
+/* Preset: one integer "level" scales all counts (level 1 ~ coarse). */
+nsxh_mesh *nsxh_mesh_cylinder_level(int dim, int level);
+/* Cube [-1,1]^3 with n cells per side x 6 tets (reference mesh/mesh-cube.geo:1-28).
+ * Boundary ids 0..5: x=-1:0, x=+1:1, y=+1:2, y=-1:3 (Neumann side, reference Convergence3D.cpp:308), z=-1:4, z=+1:5. */
+nsxh_mesh *nsxh_mesh_cube(int n);
+/* Generic box [x0,x1]x[y0,y1](x[z0,z1]) split into simplices; boundary ids as for the channel (no obstacle). */
+nsxh_mesh *nsxh_mesh_box(int dim, int nx, int ny, int nz, const double *lo, const double *hi);
+/* Gmsh MSH 2.2 / 4.1 ASCII reader for triangle / tetrahedron meshes with physical ids (reference NavierStokes3D.cpp:10-14). */
+nsxh_mesh *nsxh_mesh_read_msh(const char *path);
+void nsxh_mesh_free(nsxh_mesh *);
+
+int nsxh_mesh_dim(const nsxh_mesh *);
+int nsxh_mesh_n_vertices(const nsxh_mesh *);
+int nsxh_mesh_n_cells(const nsxh_mesh *);
+int nsxh_mesh_n_bfaces(const nsxh_mesh *);
+const double *nsxh_mesh_vertices(const nsxh_mesh *);   /* [n_vertices][dim] */
+const int32_t *nsxh_mesh_cells(const nsxh_mesh *);     /* [n_cells][dim+1], positively oriented */
+const int32_t *nsxh_mesh_bfaces(const nsxh_mesh *);    /* [n_bfaces][dim] vertex ids */
+const int32_t *nsxh_mesh_bface_ids(const nsxh_mesh *); /* [n_bfaces] boundary id */
+const int32_t *nsxh_mesh_bface_cells(const nsxh_mesh *); /* [n_bfaces] adjacent cell */
+const int32_t *nsxh_mesh_subdomain(const nsxh_mesh *); /* [n_cells] */
+
+/* Partition cells into n_parts * n_sub subdomains by recursive coordinate bisection of the
+ * cell centroids (stands in for GridTools::partition_triangulation / METIS, reference
+ * NavierStokes3D.cpp:16): first n_parts "ranks" (GPUs), then n_sub blocks inside each.
+ * subdomain id = part * n_sub + sub. */
+int nsxh_mesh_partition(nsxh_mesh *, int n_parts, int n_sub);
+
+/* ---- DoF handler: Taylor-Hood P2/P1 (FESystem(FE_SimplexP(2)^dim, FE_SimplexP(1)), reference NavierStokes3D.cpp:31-36) ---- */
+
+/* distribute_dofs + DoFRenumbering::component_wise(block {0,..,0,1}) (reference :62-69), numbered
+ * subdomain by subdomain exactly as an MPI run with one rank per subdomain would be. */
+nsxh_dofs *nsxh_distribute_dofs(const nsxh_mesh *);
+void nsxh_dofs_free(nsxh_dofs *);
+
+int nsxh_dofs_per_cell(const nsxh_dofs *);   /* 15 (2D) / 34 (3D) */
+int nsxh_n_nodes_p2(const nsxh_dofs *);      /* scalar P2 nodes; n_u = dim * this */
+int nsxh_n_nodes_p1(const nsxh_dofs *);      /* = n_p */
+int nsxh_n_u(const nsxh_dofs *);
+int nsxh_n_p(const nsxh_dofs *);
+const int32_t *nsxh_cell_dofs(const nsxh_dofs *);      /* [n_cells][dofs_per_cell] global dof indices, FESystem local order */
+const double *nsxh_cell_coords(const nsxh_dofs *);     /* [n_cells][dim+1][dim] */
+const double *nsxh_support_points(const nsxh_dofs *);  /* [n_u+n_p][dim] support point of every dof */
+const int32_t *nsxh_node_owner(const nsxh_dofs *);     /* [n_nodes_p2] owning subdomain */
+const int32_t *nsxh_pnode_owner(const nsxh_dofs *);    /* [n_nodes_p1] owning subdomain */
+const int32_t *nsxh_owned_u_ptr(const nsxh_dofs *);    /* [n_subdomains+1] P2-node ranges owned by each subdomain */
+const int32_t *nsxh_owned_p_ptr(const nsxh_dofs *);    /* [n_subdomains+1] P1-node ranges */
+int nsxh_n_subdomains(const nsxh_dofs *);
+
+/* Boundary dofs of one boundary id (what VectorTools::interpolate_boundary_values visits,
+ * reference NavierStokes3D.cpp:334-351), velocity components only, sorted ascending.
+ * Returns the count; *dofs is owned by the dof object. */
+int nsxh_boundary_dofs(nsxh_dofs *, int boundary_id, const int32_t **dofs);
+
+/* Block sparsity of the reference (DoFTools::make_sparsity_pattern with all couplings but (p,p),
+ * reference NavierStokes3D.cpp:109-124): block 0=(0,0) n_u x n_u, 1=(0,1) n_u x n_p, 2=(1,0) n_p x n_u,
+ * 3 = pressure-mass (1,1) n_p x n_p (:127-142). CSR with sorted columns. */
+int nsxh_reference_sparsity(nsxh_dofs *, int block, const int32_t **rowptr, const int32_t **colind);
+
+/* ---- reference-element tables (what FEValues evaluates once per run) ---- */
+
+/* rule: 0 = cell rule QGaussSimplex<dim>(3) stand-in (degree 5: 7 pts in 2D, 14 pts in 3D; see DESIGN.md note Q),
+ *       1 = face rule QGaussSimplex<dim-1>(3) stand-in mapped onto every face of the reference cell,
+ *       2 = high-order conical rule (error norms; reference Convergence3D.cpp:772). */
+nsxh_tables *nsxh_tables_create(int dim, int rule, int order);
+void nsxh_tables_free(nsxh_tables *);
+int nsxh_tables_n_q(const nsxh_tables *);
+int nsxh_tables_n_p2(const nsxh_tables *);  /* 6 / 10 */
+int nsxh_tables_n_p1(const nsxh_tables *);  /* 3 / 4  */
+const double *nsxh_tables_points(const nsxh_tables *);   /* [n_q][dim] */
+const double *nsxh_tables_weights(const nsxh_tables *);  /* [n_q] (sum = reference cell volume) */
+const double *nsxh_tables_N2(const nsxh_tables *);       /* [n_q][n_p2] */
+const double *nsxh_tables_dN2(const nsxh_tables *);      /* [n_q][n_p2][dim] reference gradients */
+const double *nsxh_tables_N1(const nsxh_tables *);       /* [n_q][n_p1] */
+const double *nsxh_tables_dN1(const nsxh_tables *);      /* [n_q][n_p1][dim] */
+/* face rule only: n_q = n_faces * n_qf; face f uses points [f*n_qf, (f+1)*n_qf) */
+int nsxh_tables_n_qf(const nsxh_tables *);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

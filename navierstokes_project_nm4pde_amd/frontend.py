@@ -1,0 +1,205 @@
+"""numpy view of the host front-end (include/nsx_host.h): meshes, DoF tables, FE tables.
+
+Mirrors the outputs of the reference's ``NavierStokes::setup()``
+(reference Navier-Stokes/src/NavierStokes3D.cpp:2-157).
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import HOST_SO, load
+
+_i32p = C.POINTER(C.c_int32)
+_f64p = C.POINTER(C.c_double)
+
+
+def _lib():
+    lib = load(HOST_SO)
+    if getattr(lib, "_nsxh_ready", False):
+        return lib
+    vp = C.c_void_p
+    sig = {
+        "nsxh_mesh_cylinder": (vp, [C.c_int] * 8 + [C.c_double] * 2),
+        "nsxh_mesh_cylinder_level": (vp, [C.c_int, C.c_int]),
+        "nsxh_mesh_cube": (vp, [C.c_int]),
+        "nsxh_mesh_box": (vp, [C.c_int] * 4 + [_f64p, _f64p]),
+        "nsxh_mesh_read_msh": (vp, [C.c_char_p]),
+        "nsxh_mesh_free": (None, [vp]),
+        "nsxh_mesh_dim": (C.c_int, [vp]),
+        "nsxh_mesh_n_vertices": (C.c_int, [vp]),
+        "nsxh_mesh_n_cells": (C.c_int, [vp]),
+        "nsxh_mesh_n_bfaces": (C.c_int, [vp]),
+        "nsxh_mesh_vertices": (_f64p, [vp]),
+        "nsxh_mesh_cells": (_i32p, [vp]),
+        "nsxh_mesh_bfaces": (_i32p, [vp]),
+        "nsxh_mesh_bface_ids": (_i32p, [vp]),
+        "nsxh_mesh_bface_cells": (_i32p, [vp]),
+        "nsxh_mesh_subdomain": (_i32p, [vp]),
+        "nsxh_mesh_partition": (C.c_int, [vp, C.c_int, C.c_int]),
+        "nsxh_distribute_dofs": (vp, [vp]),
+        "nsxh_dofs_free": (None, [vp]),
+        "nsxh_dofs_per_cell": (C.c_int, [vp]),
+        "nsxh_n_nodes_p2": (C.c_int, [vp]),
+        "nsxh_n_nodes_p1": (C.c_int, [vp]),
+        "nsxh_n_u": (C.c_int, [vp]),
+        "nsxh_n_p": (C.c_int, [vp]),
+        "nsxh_cell_dofs": (_i32p, [vp]),
+        "nsxh_cell_coords": (_f64p, [vp]),
+        "nsxh_support_points": (_f64p, [vp]),
+        "nsxh_node_owner": (_i32p, [vp]),
+        "nsxh_pnode_owner": (_i32p, [vp]),
+        "nsxh_owned_u_ptr": (_i32p, [vp]),
+        "nsxh_owned_p_ptr": (_i32p, [vp]),
+        "nsxh_n_subdomains": (C.c_int, [vp]),
+        "nsxh_boundary_dofs": (C.c_int, [vp, C.c_int, C.POINTER(_i32p)]),
+        "nsxh_reference_sparsity": (C.c_int, [vp, C.c_int, C.POINTER(_i32p), C.POINTER(_i32p)]),
+        "nsxh_tables_create": (vp, [C.c_int, C.c_int, C.c_int]),
+        "nsxh_tables_free": (None, [vp]),
+        "nsxh_tables_n_q": (C.c_int, [vp]),
+        "nsxh_tables_n_qf": (C.c_int, [vp]),
+        "nsxh_tables_n_p2": (C.c_int, [vp]),
+        "nsxh_tables_n_p1": (C.c_int, [vp]),
+        "nsxh_tables_points": (_f64p, [vp]),
+        "nsxh_tables_weights": (_f64p, [vp]),
+        "nsxh_tables_N2": (_f64p, [vp]),
+        "nsxh_tables_dN2": (_f64p, [vp]),
+        "nsxh_tables_N1": (_f64p, [vp]),
+        "nsxh_tables_dN1": (_f64p, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    lib._nsxh_ready = True
+    return lib
+
+
+def _arr(ptr, shape, dtype):
+    n = int(np.prod(shape))
+    if n == 0:
+        return np.zeros(shape, dtype=dtype)
+    return np.ctypeslib.as_array(ptr, shape=(n,)).reshape(shape).copy()
+
+
+class Mesh:
+    """Simplicial mesh with boundary ids (0 inlet, 1 outlet, 2 walls, 3 obstacle)."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise ValueError("mesh construction failed (bad parameters or unreadable file)")
+        self._h = handle
+        self._lib = _lib()
+        self.refresh()
+
+    def refresh(self):
+        L, h = self._lib, self._h
+        self.dim = L.nsxh_mesh_dim(h)
+        nv, nc, nb = L.nsxh_mesh_n_vertices(h), L.nsxh_mesh_n_cells(h), L.nsxh_mesh_n_bfaces(h)
+        self.vertices = _arr(L.nsxh_mesh_vertices(h), (nv, self.dim), np.float64)
+        self.cells = _arr(L.nsxh_mesh_cells(h), (nc, self.dim + 1), np.int32)
+        self.bfaces = _arr(L.nsxh_mesh_bfaces(h), (nb, self.dim), np.int32)
+        self.bface_ids = _arr(L.nsxh_mesh_bface_ids(h), (nb,), np.int32)
+        self.bface_cells = _arr(L.nsxh_mesh_bface_cells(h), (nb,), np.int32)
+        self.subdomain = _arr(L.nsxh_mesh_subdomain(h), (nc,), np.int32)
+
+    @classmethod
+    def cylinder(cls, dim, level=1, **kw):
+        L = _lib()
+        if kw:
+            a = dict(m=4, nr=2, nxu=2, nxd=10, nyb=1, nyt=1, nz=4, grade_x=2.0, grade_r=2.0)
+            a.update(kw)
+            return cls(L.nsxh_mesh_cylinder(dim, a["m"], a["nr"], a["nxu"], a["nxd"], a["nyb"], a["nyt"], a["nz"],
+                                            a["grade_x"], a["grade_r"]))
+        return cls(L.nsxh_mesh_cylinder_level(dim, level))
+
+    @classmethod
+    def cube(cls, n):
+        return cls(_lib().nsxh_mesh_cube(n))
+
+    @classmethod
+    def box(cls, dim, n, lo=None, hi=None):
+        n = list(n) + [1] * (3 - len(n))
+        lo = np.asarray(lo if lo is not None else [0.0] * dim, dtype=np.float64)
+        hi = np.asarray(hi if hi is not None else [1.0] * dim, dtype=np.float64)
+        return cls(_lib().nsxh_mesh_box(dim, n[0], n[1], n[2], lo.ctypes.data_as(_f64p), hi.ctypes.data_as(_f64p)))
+
+    @classmethod
+    def read_msh(cls, path):
+        return cls(_lib().nsxh_mesh_read_msh(str(path).encode()))
+
+    def partition(self, n_parts=1, n_sub=1):
+        rc = self._lib.nsxh_mesh_partition(self._h, n_parts, n_sub)
+        if rc != 0:
+            raise ValueError("partition failed (rc=%d)" % rc)
+        self.refresh()
+        return self
+
+    def __del__(self):
+        try:
+            self._lib.nsxh_mesh_free(self._h)
+        except Exception:
+            pass
+
+
+class DoFs:
+    """Taylor-Hood P2/P1 DoF tables (FESystem local order; velocity block then pressure block)."""
+
+    def __init__(self, mesh):
+        L = _lib()
+        self._lib, self.mesh = L, mesh
+        self._h = h = L.nsxh_distribute_dofs(mesh._h)
+        self.dim = mesh.dim
+        nc = mesh.cells.shape[0]
+        self.n_cells = nc
+        self.dofs_per_cell = L.nsxh_dofs_per_cell(h)
+        self.n_nodes_p2, self.n_nodes_p1 = L.nsxh_n_nodes_p2(h), L.nsxh_n_nodes_p1(h)
+        self.n_u, self.n_p = L.nsxh_n_u(h), L.nsxh_n_p(h)
+        self.n_dofs = self.n_u + self.n_p
+        self.cell_dofs = _arr(L.nsxh_cell_dofs(h), (nc, self.dofs_per_cell), np.int32)
+        self.cell_coords = _arr(L.nsxh_cell_coords(h), (nc, self.dim + 1, self.dim), np.float64)
+        self.support_points = _arr(L.nsxh_support_points(h), (self.n_dofs, self.dim), np.float64)
+        self.n_subdomains = L.nsxh_n_subdomains(h)
+        self.node_owner = _arr(L.nsxh_node_owner(h), (self.n_nodes_p2,), np.int32)
+        self.pnode_owner = _arr(L.nsxh_pnode_owner(h), (self.n_nodes_p1,), np.int32)
+        self.owned_u_ptr = _arr(L.nsxh_owned_u_ptr(h), (self.n_subdomains + 1,), np.int32)
+        self.owned_p_ptr = _arr(L.nsxh_owned_p_ptr(h), (self.n_subdomains + 1,), np.int32)
+
+    def boundary_dofs(self, boundary_id):
+        p = _i32p()
+        n = self._lib.nsxh_boundary_dofs(self._h, int(boundary_id), C.byref(p))
+        return _arr(p, (n,), np.int32)
+
+    def reference_sparsity(self, block):
+        """CSR graph of block 0=(0,0), 1=(0,1), 2=(1,0), 3=pressure mass, in the reference's padded layout."""
+        rp, ci = _i32p(), _i32p()
+        n = self._lib.nsxh_reference_sparsity(self._h, int(block), C.byref(rp), C.byref(ci))
+        rowptr = _arr(rp, (n + 1,), np.int32)
+        return rowptr, _arr(ci, (int(rowptr[-1]),), np.int32)
+
+    def __del__(self):
+        try:
+            self._lib.nsxh_dofs_free(self._h)
+        except Exception:
+            pass
+
+
+class Tables:
+    """Reference-element shape tables at quadrature points (data, not code, for the device kernels)."""
+
+    CELL, FACE, HIGH = 0, 1, 2
+
+    def __init__(self, dim, rule=0, order=0):
+        L = _lib()
+        h = L.nsxh_tables_create(dim, rule, order)
+        if not h:
+            raise ValueError("bad table request")
+        self.dim = dim
+        nq, n2, n1 = L.nsxh_tables_n_q(h), L.nsxh_tables_n_p2(h), L.nsxh_tables_n_p1(h)
+        self.n_q, self.n_p2, self.n_p1, self.n_qf = nq, n2, n1, L.nsxh_tables_n_qf(h)
+        self.points = _arr(L.nsxh_tables_points(h), (nq, dim), np.float64)
+        self.weights = _arr(L.nsxh_tables_weights(h), (nq,), np.float64)
+        self.N2 = _arr(L.nsxh_tables_N2(h), (nq, n2), np.float64)
+        self.dN2 = _arr(L.nsxh_tables_dN2(h), (nq, n2, dim), np.float64)
+        self.N1 = _arr(L.nsxh_tables_N1(h), (nq, n1), np.float64)
+        self.dN1 = _arr(L.nsxh_tables_dN1(h), (nq, n1, dim), np.float64)
+        L.nsxh_tables_free(h)

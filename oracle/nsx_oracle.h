@@ -1,0 +1,94 @@
+/* nsx_oracle.h — CPU restatement of the reference's per-time-step hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (navierstokes_project_nm4pde_amd/, include/nsx.h)
+ * may include, link or call this; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
+ *
+ * PARITY UNPINNED: the reference (deal.II + Trilinos) cannot be built in this image and ships no tests,
+ * golden vectors or fixtures, so this restatement is pinned only by closed-form
+ * element matrices, polynomial patch tests and the Ethier-Steinmann manufactured solution (tests/).
+ *
+ * Each function cites the reference lines it follows.  Short names:
+ *   NS3D = Navier-Stokes/src/NavierStokes3D.cpp   NS2D = .../NavierStokes2D.cpp
+ *   Conv = .../Convergence3D.cpp                  Prec = Navier-Stokes/include/Preconditioners.hpp
+ * Matrices use the reference's own layout: 2x2 block CSR in the global deal.II numbering
+ * (velocity block with ALL component couplings stored, NS3D:109-124), double precision, int32 indices.
+ */
+#ifndef NSX_ORACLE_H
+#define NSX_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc orc;
+
+enum { ORC_TEMAM = 1, ORC_DOUBLE_CONVECTION = 2 };
+enum { ORC_YOSIDA = 0, ORC_SIMPLE = 1, ORC_AYOSIDA = 2, ORC_ASIMPLE = 3 };
+
+typedef struct {
+  int outer_iterations;      /* solver_control.last_step(), NS3D:636 */
+  int inner_F_iterations;    /* summed over all inner GMRES(F) solves */
+  int inner_S_iterations;    /* summed over all inner CG/GMRES(S) solves */
+  int n_F_solves, n_S_solves;
+  double final_residual;     /* last preconditioned residual estimate */
+  double t_prec, t_solve;    /* seconds, NS3D:558-577 */
+  int status;                /* 0 ok, 1 outer not converged, 2 inner not converged */
+} orc_stats;
+
+/* Problem container: copies every array.  Graph block ids: 0=(0,0) 1=(0,1) 2=(1,0) 3=pressure mass (1,1). */
+orc *orc_create(int dim, int n_cells, int dofs_per_cell, int n_u, int n_p, const int32_t *cell_dofs,
+                const double *cell_coords, int n_q, int n_p2, int n_p1, const double *N2, const double *dN2,
+                const double *N1, const double *weights, const int32_t *const rowptr[4], const int32_t *const colind[4],
+                double nu, double deltat);
+void orc_destroy(orc *);
+
+/* Virtual MPI ranks: velocity rows [dim*u_ptr[r], dim*u_ptr[r+1]) and pressure rows [p_ptr[r], p_ptr[r+1])
+ * belong to rank r (Ifpack overlap-0 ILU is per rank; apply_boundary_values' diagonal scan is per rank). */
+void orc_set_ranks(orc *, int n_ranks, const int32_t *u_ptr_nodes, const int32_t *p_ptr_nodes);
+/* Optional coarser ILU blocks for the Schur matrix (unions of consecutive ranks); default = ranks. */
+void orc_set_schur_blocks(orc *, int n_blocks, const int32_t *p_ptr_nodes);
+
+/* NavierStokes::assemble (NS3D:163-324 / NS2D:164-325 / Conv:187-357), without the Dirichlet part. */
+void orc_assemble(orc *, int flags);
+/* NavierStokes::assemble_time_step (NS3D:361-512 / NS2D:360-493 / Conv:396-551), without the Dirichlet part. */
+void orc_assemble_time_step(orc *, int flags);
+/* system_rhs.add(...) hook for the Neumann face term (Conv:309-331), values computed by the caller. */
+void orc_add_rhs(orc *, int n, const int32_t *dofs, const double *vals);
+/* MatrixTools::apply_boundary_values(bv, system_matrix, solution, system_rhs, false) (NS3D:353,541). */
+void orc_apply_boundary_values(orc *, int n, const int32_t *dofs, const double *vals);
+/* NavierStokes::solve_time_step (NS3D:546-640).  tol_abs=1e-4, inner_rtol=1e-2 are the reference's values. */
+void orc_solve_time_step(orc *, int prec_type, double tol_abs, double inner_rtol, int maxiter, int inner_maxiter,
+                         orc_stats *stats);
+
+/* state access (pointers into the object) */
+double *orc_solution(orc *);        /* ghosted `solution`  (n_u+n_p) */
+double *orc_solution_owned(orc *);  /* `solution_owned` */
+double *orc_rhs(orc *);             /* `system_rhs` */
+/* which: 0 system 1 mass 2 convection 3 stiffness 4 pressure_mass(block must be 3); block as above */
+double *orc_matrix_values(orc *, int which, int block);
+/* negative_S_tilde of the last preconditioner initialize(): CSR arrays owned by the object */
+int orc_schur(orc *, const int32_t **rowptr, const int32_t **colind, const double **values);
+/* ILU(0) factors of F from the last initialize(), in the CSR layout of block (0,0):
+ * strict-lower = L, diagonal = 1/d, strict-upper = U scaled by 1/d (Ifpack_ILU storage). Entries outside the
+ * rank-diagonal blocks are 0. */
+const double *orc_ilu_F(orc *);
+const double *orc_ilu_S(orc *);
+
+/* ---- stand-alone kernels (unit parity tests) ---- */
+void orc_spmv(int n_rows, const int32_t *rowptr, const int32_t *colind, const double *vals, const double *x, double *y);
+void orc_system_vmult(orc *, double *dst, const double *src);
+/* Ifpack-style block ILU(0): out has the layout of vals (see orc_ilu_F). */
+void orc_ilu0_factor(int n_rows, const int32_t *rowptr, const int32_t *colind, const double *vals, int n_blocks,
+                     const int32_t *block_ptr, double *out);
+void orc_ilu0_solve(int n_rows, const int32_t *rowptr, const int32_t *colind, const double *lu, int n_blocks,
+                    const int32_t *block_ptr, const double *b, double *x);
+/* preconditioner application alone (after an orc_solve_time_step or orc_prec_initialize) */
+void orc_prec_initialize(orc *, int prec_type);
+void orc_prec_vmult(orc *, int prec_type, double inner_rtol, int inner_maxiter, double *dst, const double *src,
+                    orc_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
