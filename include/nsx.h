@@ -1,0 +1,177 @@
+/* nsx.h — C-ABI of libnsx.so, the MI355X (gfx950) implementation of the per-time-step hot path of
+ * lelecaruso/NavierStokes_Project_NM4PDE:
+ *
+ *     NavierStokes::assemble(time)            reference Navier-Stokes/src/NavierStokes3D.cpp:163-356
+ *     NavierStokes::assemble_time_step(time)  reference Navier-Stokes/src/NavierStokes3D.cpp:361-544
+ *     NavierStokes::solve_time_step()         reference Navier-Stokes/src/NavierStokes3D.cpp:546-640
+ *     Precondition{Yosida,SIMPLE,aYosida,aSIMPLE}::initialize / ::vmult
+ *                                              reference Navier-Stokes/include/Preconditioners.hpp:118-534
+ * (2D: src/NavierStokes2D.cpp:164-639; convergence study: src/Convergence3D.cpp:187-680.)
+ *
+ * The reference has no plugin / FFI layer: the seams a replacement binds to are those member functions
+ * (SURVEY.md section 8b).  Every entry point below names the member (file:line) whose work it performs;
+ * INTEGRATION.md shows the deal.II-side adaptor that forwards the three members to these calls.
+ *
+ * Conventions: extern "C"; opaque handle, one per GPU / rank; every call returns 0 (NSX_OK) or a negative
+ * nsx_status, with a message available from nsx_last_error(); no exception crosses the boundary; host
+ * arrays are borrowed for the duration of the call only; device memory is owned by the handle; calls on
+ * one handle are not thread-safe.  Indices are int32 (as Epetra's), values are FP64.
+ *
+ * Numbering contract (what deal.II's DoFHandler provides after DoFRenumbering::component_wise by block,
+ * reference NavierStokes3D.cpp:62-69): velocity dofs first, [0, n_u), the `dim` components of one P2 node
+ * consecutive (dof = dim * node + c); pressure dofs after them, dof = n_u + p1_node.  Local dof order on a
+ * cell is FESystem's: per vertex the dim velocity components then the pressure, then per line the dim
+ * velocity components (34 dofs on a tetrahedron, 15 on a triangle).
+ */
+#ifndef NSX_H
+#define NSX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nsx_handle nsx_handle;
+
+typedef enum {
+  NSX_OK = 0,
+  NSX_ERR_ARG = -1,          /* bad argument / call order */
+  NSX_ERR_HIP = -2,          /* HIP runtime error (message has the HIP error string) */
+  NSX_ERR_UNSUPPORTED = -3,  /* valid input this build has no kernel for (e.g. quadrature size) */
+  NSX_ERR_NOCONV = -4,       /* a Krylov solver hit its iteration limit: deal.II would throw SolverControl::NoConvergence */
+  NSX_ERR_NUMERIC = -5,      /* NaN / zero pivot */
+  NSX_ERR_COMM = -6          /* RCCL error */
+} nsx_status;
+
+/* preconditioner_type of NavierStokes::solve_time_step (reference NavierStokes3D.cpp:562-634) */
+typedef enum { NSX_PREC_YOSIDA = 0, NSX_PREC_SIMPLE = 1, NSX_PREC_AYOSIDA = 2, NSX_PREC_ASIMPLE = 3 } nsx_prec;
+
+/* assembly variants: which terms the reference's three executables put into the convection matrix */
+enum {
+  NSX_TEMAM = 1,             /* 0.5 (div u_n) (phi_i . phi_j): NS3D first step only (:255); NS2D / Conv every step (NS2D:446, Conv:490) */
+  NSX_DOUBLE_CONVECTION = 2  /* Convergence3D.cpp:277 + :284 add the convective term twice in the first assembly */
+};
+
+typedef struct {
+  int dim;          /* 2 or 3 */
+  int device;       /* HIP device ordinal */
+  double nu;        /* kinematic viscosity (reference NavierStokes3D.hpp:162) */
+  double deltat;    /* time step (reference NavierStokes3D.hpp:191) */
+} nsx_params;
+
+typedef struct {
+  int outer_iterations;    /* solver_control.last_step()  (reference NavierStokes3D.cpp:636) */
+  int inner_F_iterations;  /* sum over all inner GMRES(F) solves of the step */
+  int inner_S_iterations;  /* sum over all inner CG / GMRES(S) solves of the step */
+  int n_F_solves, n_S_solves;
+  double final_residual;   /* last preconditioned residual norm seen by the outer GMRES */
+  double t_prec;           /* seconds, preconditioner initialize (reference NavierStokes3D.cpp:558-572, time_prec) */
+  double t_solve;          /* seconds, outer solve               (reference NavierStokes3D.cpp:573-577, time_solve) */
+  int status;              /* 0 ok, 1 outer GMRES not converged, 2 an inner solve not converged */
+} nsx_solve_stats;
+
+/* ---- life cycle ---- */
+int nsx_create(const nsx_params *params, nsx_handle **out);
+int nsx_destroy(nsx_handle *h);
+const char *nsx_last_error(const nsx_handle *h); /* h may be NULL: error of the last failed nsx_create */
+const char *nsx_version(void);
+
+/* ---- setup: the outputs of NavierStokes::setup() (reference NavierStokes3D.cpp:2-157) ---- */
+
+/* FEValues tables on the reference cell, as data (reference NavierStokes3D.cpp:31-50, 172-175):
+ * scalar P2 values N2[n_q][n_p2], reference gradients dN2[n_q][n_p2][dim], scalar P1 values N1[n_q][n_p1],
+ * quadrature weights w[n_q] (sum = volume of the reference simplex).  n_p2 = 6/10, n_p1 = 3/4. */
+int nsx_set_tables(nsx_handle *h, int n_q, int n_p2, int n_p1, const double *N2, const double *dN2,
+                   const double *N1, const double *weights);
+
+/* Mesh + DoF tables: cell->get_dof_indices for every locally owned cell (reference NavierStokes3D.cpp:304,494)
+ * and the cell's vertex coordinates (affine map).  Builds the sparsity graphs of the three blocks
+ * (reference NavierStokes3D.cpp:109-124) internally.  cell_dofs[n_cells][dofs_per_cell], cell_coords[n_cells][dim+1][dim]. */
+int nsx_set_mesh(nsx_handle *h, int n_cells, int dofs_per_cell, const int32_t *cell_dofs, const double *cell_coords,
+                 int n_u, int n_p);
+
+/* MPI-rank structure of the run being reproduced: velocity P2-node ranges u_ptr[n_ranks+1] and P1-node
+ * ranges p_ptr[n_ranks+1] owned by each rank.  They define (a) the blocks of the per-rank Ifpack ILU(0)
+ * (TrilinosWrappers::PreconditionILU, overlap 0: reference Preconditioners.hpp:215-216 and SURVEY D4) and
+ * (b) the per-rank diagonal scan of MatrixTools::apply_boundary_values.  Default: one rank.
+ * On one GPU this lets the ILU run as n_ranks independent triangular solves, exactly what `mpirun -n n_ranks`
+ * of the reference computes. */
+int nsx_set_ranks(nsx_handle *h, int n_ranks, const int32_t *u_ptr, const int32_t *p_ptr);
+/* Optional: coarser blocks for the Schur-complement ILU (unions of consecutive ranks); default = the ranks. */
+int nsx_set_schur_blocks(nsx_handle *h, int n_blocks, const int32_t *p_ptr);
+
+/* ---- state ---- */
+/* `solution` (ghosted) and `solution_owned` (reference NavierStokes3D.hpp:245-248), length n_u + n_p. */
+int nsx_set_solution(nsx_handle *h, const double *solution_owned);  /* also does solution = solution_owned (NavierStokes3D.cpp:696-697) */
+int nsx_get_solution(nsx_handle *h, double *solution_owned);
+int nsx_get_solution_ghosted(nsx_handle *h, double *solution);
+int nsx_get_rhs(nsx_handle *h, double *system_rhs);
+int nsx_set_rhs(nsx_handle *h, const double *system_rhs);
+
+/* ---- the hot path ---- */
+
+/* NavierStokes::assemble(time) without its Dirichlet block (reference NavierStokes3D.cpp:163-324):
+ * mass/deltat, nu*stiffness, convection(u_n) (+Temam), -B^T / B, pressure mass; system = blocks + M + C + K; rhs. */
+int nsx_assemble(nsx_handle *h, int flags);
+/* NavierStokes::assemble_time_step(time) without its Dirichlet block (reference NavierStokes3D.cpp:361-512):
+ * new convection(u_n) and rhs; system = system - C_old + C_new. */
+int nsx_assemble_time_step(nsx_handle *h, int flags);
+/* system_rhs.add(dof_indices, cell_rhs) for terms integrated by the caller (Neumann face term, Convergence3D.cpp:309-331). */
+int nsx_add_rhs(nsx_handle *h, int n, const int32_t *dofs, const double *values);
+/* MatrixTools::apply_boundary_values(boundary_values, system_matrix, solution, system_rhs, false)
+ * (reference NavierStokes3D.cpp:353,541).  (dofs[k], values[k]) is the std::map, sorted by dof; every component
+ * of a constrained P2 node must be present (the reference's ComponentMask always selects all of them). */
+int nsx_apply_boundary_values(nsx_handle *h, int n, const int32_t *dofs, const double *values);
+/* NavierStokes::solve_time_step() (reference NavierStokes3D.cpp:546-640): previous_solution = solution;
+ * preconditioner.initialize(...); SolverGMRES(solver_control(maxiter, tol_abs)).solve(system_matrix,
+ * solution_owned, system_rhs, preconditioner); solution = solution_owned.
+ * Reference values: tol_abs = 1e-4, inner_rtol = 1e-2, maxiter = 100000, inner_maxiter = 100000 (10000 for (a)SIMPLE). */
+int nsx_solve_time_step(nsx_handle *h, int prec_type, double tol_abs, double inner_rtol, int maxiter,
+                        int inner_maxiter, nsx_solve_stats *stats);
+
+/* Pieces of solve_time_step, exposed for parity tests and for callers that drive deal.II's own SolverGMRES
+ * through the preconditioner concept (initialize / vmult, reference Preconditioners.hpp:122-126,152-153). */
+int nsx_prec_initialize(nsx_handle *h, int prec_type);
+int nsx_prec_vmult(nsx_handle *h, int prec_type, double inner_rtol, int inner_maxiter, double *dst, const double *src,
+                   nsx_solve_stats *stats);
+int nsx_system_vmult(nsx_handle *h, double *dst, const double *src); /* BlockSparseMatrix::vmult, host vectors n_u+n_p */
+/* One PreconditionILU::vmult with the factors of the last initialize: which = 0 (F, length n_u) or 1 (S, length n_p). */
+int nsx_ilu_apply(nsx_handle *h, int which, double *dst, const double *src);
+
+/* ---- export in the reference's own layout (Trilinos block CSR with all velocity couplings stored) ---- */
+/* which: 0 system_matrix, 1 mass_matrix, 2 convection_matrix, 3 stiffness_matrix, 4 pressure_mass
+ * block: 0=(0,0) n_u x n_u, 1=(0,1) n_u x n_p, 2=(1,0) n_p x n_u, 3=(1,1) (pressure_mass only).
+ * The caller passes the CSR graph it wants filled (e.g. Epetra's ExtractCrsDataPointers); entries that are
+ * structural zeros in the reference (cross-component couplings) are written as 0. */
+int nsx_export_block(nsx_handle *h, int which, int block, int n_rows, const int32_t *rowptr, const int32_t *colind,
+                     double *values);
+/* negative_S_tilde of the last initialize (reference Preconditioners.hpp:144,248,358,468): query nnz, then fetch. */
+int nsx_schur_nnz(nsx_handle *h, int64_t *nnz);
+int nsx_schur_get(nsx_handle *h, int32_t *rowptr, int32_t *colind, double *values);
+/* ILU(0) factors of the last initialize in the compact layout of the scalar velocity graph / the Schur graph
+ * (strict lower = L, diagonal = 1/d, strict upper = U/d as Ifpack stores them); graph via nsx_scalar_graph. */
+int nsx_scalar_graph_nnz(nsx_handle *h, int which, int64_t *nnz); /* which: 0 velocity scalar P2 graph, 1 Schur graph */
+int nsx_scalar_graph(nsx_handle *h, int which, int32_t *rowptr, int32_t *colind);
+int nsx_ilu_get(nsx_handle *h, int which, double *values);
+
+/* ---- measurement ---- */
+/* Per-kernel HIP-event timing of the hot path (bench.py roofline): enable, run, then read name/count/total-ms. */
+int nsx_profile_enable(nsx_handle *h, int on);
+int nsx_profile_reset(nsx_handle *h);
+int nsx_profile_count(nsx_handle *h);
+int nsx_profile_get(nsx_handle *h, int i, const char **name, int64_t *launches, double *total_ms, double *bytes_per_launch);
+
+/* ---- multi-GPU (one process per GPU, RCCL over xGMI) ---- */
+int nsx_comm_unique_id(uint8_t id[128]);                       /* rank 0: ncclGetUniqueId */
+int nsx_comm_init(nsx_handle *h, int rank, int world, const uint8_t id[128]);
+/* Distributed mesh: this rank's cells (owned + one ghost layer) in GLOBAL dof numbering plus the global
+ * ownership ranges of all ranks; replaces nsx_set_mesh + nsx_set_ranks for world > 1. */
+int nsx_set_mesh_distributed(nsx_handle *h, int n_cells, int dofs_per_cell, const int32_t *cell_dofs,
+                             const double *cell_coords, int n_u_global, int n_p_global, int world,
+                             const int32_t *gpu_u_ptr, const int32_t *gpu_p_ptr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

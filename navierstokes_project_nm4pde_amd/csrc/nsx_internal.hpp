@@ -1,0 +1,241 @@
+// nsx_internal.hpp — private state of a libnsx handle (C-ABI: include/nsx.h).
+//
+// HBM layout (all FP64 values, int32 indices; N2 = scalar P2 nodes, NP = P1 nodes, dim components interleaved):
+//   vectors        [n_u + n_p] = [N2][dim] velocity (node-major, components consecutive) then [NP] pressure
+//   A-graph        scalar P2 x P2 CSR (rowptr/colind/diag position); value arrays on it:
+//                  S0 = M/dt + nu K (static), Mass = M/dt, Stiff = nu K, Conv = C(u_n), F = system(0,0), LU_F
+//                  -> the reference stores dim^2 x as many entries (all component couplings, NS3D.cpp:109-119);
+//                     every velocity-velocity term is delta_cd (x) scalar, so one scalar operator serves dim components.
+//   G-graph        P2 x P1 CSR, dim values per entry: block (0,1) = -int psi_k d_c phi_i   (NS3D.cpp:258)
+//   B-graph        P1 x P2 CSR, dim values per entry: block (1,0) = +int psi_k d_c phi_j   (NS3D.cpp:261)
+//   S-graph        P1 x P1 CSR = structural product B*G: negative_S_tilde and its ILU(0)   (Prec.hpp:144,358)
+//   cell tables    SoA: cell_n2[a][cell], cell_n1[v][cell], geo[k][cell] (J^-1 row-major, then |det J|)
+//   gather maps    per CSR entry the list of (local entry, cell) contributions -> deterministic assembly, no atomics
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/nsx.h"
+#include "../host/graph.hpp"
+
+namespace nsx {
+
+struct Error {
+  int code;
+  std::string msg;
+};
+
+#define NSX_THROW(code_, ...)                              \
+  do {                                                     \
+    char buf_[512];                                        \
+    snprintf(buf_, sizeof(buf_), __VA_ARGS__);             \
+    throw ::nsx::Error{(code_), std::string(buf_)};        \
+  } while (0)
+
+#define HIP_CHECK(expr)                                                                                   \
+  do {                                                                                                    \
+    hipError_t e_ = (expr);                                                                               \
+    if (e_ != hipSuccess) NSX_THROW(NSX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+template <class T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  void alloc(size_t count) {
+    if (count == n && p) return;
+    release();
+    n = count;
+    HIP_CHECK(hipMalloc((void **)&p, (count ? count : 1) * sizeof(T)));
+  }
+  void zero(hipStream_t s) {
+    if (n) HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(T), s));
+  }
+  void upload(const T *src, size_t count, hipStream_t s) {
+    alloc(count);
+    if (count) HIP_CHECK(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+  }
+  void upload(const std::vector<T> &v, hipStream_t s) { upload(v.data(), v.size(), s); }
+  void download(T *dst, size_t count, hipStream_t s) const {
+    if (count) HIP_CHECK(hipMemcpyAsync(dst, p, count * sizeof(T), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+  }
+};
+
+// CSR graph resident on the device (+ host copy kept for exports / setup products)
+struct DevCsr {
+  Csr host;
+  DevBuf<int32_t> rowptr, colind, diag;  // diag: position of (i,i) (square graphs only)
+  int32_t n_rows() const { return host.n_rows; }
+  int64_t nnz() const { return host.nnz(); }
+};
+
+// Deterministic gather map: out entry e sums src[ptr[e] .. ptr[e+1]) (buffer offsets, ascending cell order).
+struct GatherMap {
+  DevBuf<int32_t> ptr, src;
+  int64_t n_out = 0, n_src = 0;
+};
+
+// Block-Jacobi ILU(0) schedule on a square graph: per block the rows sorted by dependency level.
+struct IluSchedule {
+  int n_blocks = 0, max_rows = 0;
+  std::vector<int32_t> block_ptr_h;
+  DevBuf<int32_t> block_ptr;             // [n_blocks+1] row ranges
+  DevBuf<int32_t> fwd_lvl_ptr, fwd_rows; // per block: levels of the L solve / factorisation (global arrays with offsets)
+  DevBuf<int32_t> bwd_lvl_ptr, bwd_rows; // per block: levels of the U solve
+  DevBuf<int32_t> blk_lvl_off;           // [n_blocks+1] offsets into fwd_lvl_ptr (levels per block), same for bwd
+  DevBuf<int32_t> blk_lvl_off_b;
+  int max_levels = 0;
+};
+
+struct ProfEntry {
+  int64_t launches = 0;
+  double bytes = 0;  // algorithmic bytes of one launch (last seen)
+  double ms = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct Comm;  // RCCL state (nsx_comm.hip)
+
+}  // namespace nsx
+
+struct nsx_handle {
+  nsx_params prm{};
+  std::string err;
+  hipStream_t stream = nullptr;
+  // ---- discretisation
+  int dim = 0, n_q = 0, np2 = 0, np1 = 0, dpc = 0;
+  int n_cells = 0, N2 = 0, NP = 0, n_u = 0, n_p = 0;  // local sizes (rows owned by this handle)
+  int N2_loc = 0, NP_loc = 0;                          // owned + ghost (== N2, NP on one GPU)
+  bool have_tables = false, have_mesh = false, assembled = false, prec_ready = false;
+  std::vector<double> N2_h, dN2_h, N1_h, w_h;
+  nsx::DevBuf<double> tab_N2, tab_dN2, tab_N1, tab_w, tab_N2T, tab_dN2T;  // T: [a][q] / [b][q][k]
+  nsx::DevBuf<int32_t> cell_n2, cell_n1;  // SoA [a][cell]
+  nsx::DevBuf<double> geo;                // SoA [(dim*dim+1)][cell]
+  std::vector<int32_t> cell_n2_h, cell_n1_h;
+  // ---- graphs and values
+  nsx::DevCsr gA, gG, gB, gS, gPM;
+  nsx::DevBuf<double> vS0, vMass, vStiff, vConv, vF, vG, vB, vPM, vSchur, luF, luS;
+  nsx::DevBuf<int32_t> bt_of_g;            // for every G entry (i,k): position of (k,i) in the B graph
+  nsx::GatherMap gmA, gmG, gmB, gmPM;
+  nsx::DevBuf<double> cellbuf;             // per-cell local matrices, SoA [(entry)][cell]
+  // ---- vectors (n_u + n_p)
+  nsx::DevBuf<double> sol, sol_owned, prev_sol, rhs;
+  // ---- ranks / ILU
+  std::vector<int32_t> rank_u_h, rank_p_h, sblk_h;
+  nsx::DevBuf<int32_t> rank_u;             // node units
+  nsx::IluSchedule schedF, schedS;
+  nsx::DevBuf<double> dbar;                // per-rank Dirichlet diagonal
+  nsx::DevBuf<int32_t> bc_dofs;
+  nsx::DevBuf<double> bc_vals;
+  nsx::DevBuf<double> dirmask;             // [n_u] 1 = free, 0 = constrained row of block (0,1)
+  std::vector<int32_t> bc_cache;
+  // ---- preconditioner vectors
+  nsx::DevBuf<double> diag_D, diag_D_inv, neg_diag_D_inv, lump_M, schur_w;
+  // ---- Krylov workspace
+  std::vector<nsx::DevBuf<double> *> pool;  // temporary vectors handed out by size
+  nsx::DevBuf<double> red_partial;          // reduction partials
+  nsx::DevBuf<double> scal;                 // device scalars
+  double *scal_host = nullptr;              // pinned mirror
+  // ---- profiling
+  bool prof_on = false;
+  std::map<std::string, nsx::ProfEntry> prof;
+  std::vector<std::string> prof_names;
+  // ---- comm
+  nsx::Comm *comm = nullptr;
+};
+
+namespace nsx {
+
+// RAII launch timer used by every kernel launch site.
+struct LaunchScope {
+  nsx_handle *h;
+  ProfEntry *e = nullptr;
+  hipEvent_t a = nullptr, b = nullptr;
+  LaunchScope(nsx_handle *h_, const char *name, double bytes) : h(h_) {
+    if (!h->prof_on) return;
+    e = &h->prof[name];
+    e->bytes = bytes;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    (void)hipEventRecord(a, h->stream);
+  }
+  ~LaunchScope() {
+    if (!e) return;
+    (void)hipEventRecord(b, h->stream);
+    e->launches++;
+    e->pending.emplace_back(a, b);
+  }
+};
+
+inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- kernels / steps implemented across the .hip files
+void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> &block_ptr, IluSchedule &s);
+void build_schur_graph(nsx_handle *h);
+
+// assembly (nsx_assemble.hip)
+void run_assemble(nsx_handle *h, bool first, int flags);
+void run_dirichlet(nsx_handle *h, int n, const int32_t *dofs, const double *vals);
+
+// sparse (nsx_sparse.hip)
+void spmv_F(nsx_handle *h, const double *vals, const double *x, double *y);                 // y_u = A x_u   (dim comps)
+void spmv_saddle(nsx_handle *h, const double *x, double *y);                                // full block vmult
+void spmv_G(nsx_handle *h, const double *xp, double *yu, bool accumulate);                  // y_u (+)= block(0,1) x_p
+void spmv_B(nsx_handle *h, const double *xu, double *yp);                                   // y_p = block(1,0) x_u
+void spmv_S(nsx_handle *h, const double *x, double *y);                                     // y = negative_S x
+void schur_numeric(nsx_handle *h, const double *w);                                         // S = B diag(w) G
+void ilu_factor(nsx_handle *h, const DevCsr &g, const IluSchedule &s, const double *vals, double *lu, const char *name);
+void ilu_solve(nsx_handle *h, const DevCsr &g, const IluSchedule &s, const double *lu, const double *b, double *x, int ncomp,
+               const char *name);
+void extract_diag(nsx_handle *h, const DevCsr &g, const double *vals, double *d);           // scalar diag
+void abs_rowsum(nsx_handle *h, const DevCsr &g, const double *vals, double *d);
+
+// BLAS-1 (nsx_blas.hip): scalars live in h->scal[slot]
+enum { N_SLOTS = 128 };
+void v_copy(nsx_handle *h, int n, double *d, const double *s);
+void v_zero(nsx_handle *h, int n, double *d);
+void v_add(nsx_handle *h, int n, double *d, double a, const double *v);                     // d += a v
+void v_add_dev(nsx_handle *h, int n, double *d, double a, int slot, const double *v);       // d += a*scal[slot]*v
+void v_sadd(nsx_handle *h, int n, double *d, double s, double a, const double *v);          // d = s d + a v
+void v_scale(nsx_handle *h, int n, double *d, double a);
+void v_scale_dev_inv(nsx_handle *h, int n, double *d, int slot);                            // d *= 1/scal[slot]
+void v_scale_vec(nsx_handle *h, int n, double *d, const double *f);
+void v_dot(nsx_handle *h, int n, const double *a, const double *b, int slot);               // scal[slot] = a.b
+void v_add_and_dot(nsx_handle *h, int n, double *d, double a, int aslot, const double *v, const double *w, int slot);
+                                                                                            // d += a*scal[aslot]*v ; scal[slot] = d.w
+void v_axpy_multi(nsx_handle *h, int n, double *x, int k, double *const *vs, const double *coef_host);
+double read_scalar(nsx_handle *h, int slot);
+void read_scalars(nsx_handle *h, int slot0, int count, double *out);
+void write_scalar(nsx_handle *h, int slot, double v);
+
+// solver (nsx_solve.hip)
+void prec_initialize(nsx_handle *h, int type);
+void prec_vmult(nsx_handle *h, int type, double inner_rtol, int inner_maxiter, double *dst, const double *src,
+                nsx_solve_stats *st);
+void solve_time_step(nsx_handle *h, int type, double tol, double inner_rtol, int maxiter, int inner_maxiter,
+                     nsx_solve_stats *st);
+
+// comm (nsx_comm.hip)
+void comm_allreduce_scalars(nsx_handle *h, int slot0, int count);
+void comm_halo_u(nsx_handle *h, double *x);
+void comm_halo_p(nsx_handle *h, double *x);
+void comm_destroy(nsx_handle *h);
+
+}  // namespace nsx

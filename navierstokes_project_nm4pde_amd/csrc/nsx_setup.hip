@@ -1,0 +1,568 @@
+// nsx_setup.hip — handle life cycle and the host-side setup products of libnsx:
+// sparsity graphs (reference NavierStokes3D.cpp:109-124), cell geometry, deterministic gather maps,
+// per-rank ILU(0) level schedules (Ifpack overlap-0 semantics) and the Schur pattern
+// (EpetraExt::MatrixMatrix::Multiply structural product, reference Preconditioners.hpp:144,248,358,468).
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+#include "nsx_internal.hpp"
+
+using namespace nsx;
+
+static thread_local std::string g_create_error;
+
+namespace nsx {
+
+static void upload_csr(nsx_handle *h, DevCsr &d, bool square) {
+  d.rowptr.upload(d.host.rowptr, h->stream);
+  d.colind.upload(d.host.colind, h->stream);
+  if (square) {
+    std::vector<int32_t> diag(d.host.n_rows);
+    for (int32_t i = 0; i < d.host.n_rows; ++i) {
+      diag[i] = find_in_row(d.host, i, i);
+      if (diag[i] < 0) NSX_THROW(NSX_ERR_ARG, "square graph has no diagonal entry in row %d", i);
+    }
+    d.diag.upload(diag, h->stream);
+  }
+}
+
+// contributions of every cell-local pair (r,c) to CSR entry (rows[r], cols[c]); src = plane*stride*n_cells + cell
+static void build_gather(nsx_handle *h, const Csr &g, int n_cells, int per_r, const int32_t *cell_r, int per_c,
+                         const int32_t *cell_c, int plane_stride, bool plane_rc_swapped, GatherMap &gm) {
+  const int64_t nnz = g.nnz();
+  std::vector<int32_t> ptr(nnz + 1, 0);
+  std::vector<int32_t> epos((size_t)n_cells * per_r * per_c);
+  for (int c = 0; c < n_cells; ++c)
+    for (int a = 0; a < per_r; ++a)
+      for (int b = 0; b < per_c; ++b) {
+        const int32_t e = find_in_row(g, cell_r[(size_t)c * per_r + a], cell_c[(size_t)c * per_c + b]);
+        if (e < 0) NSX_THROW(NSX_ERR_ARG, "internal: cell pair not in graph");
+        epos[((size_t)c * per_r + a) * per_c + b] = e;
+        ptr[e + 1]++;
+      }
+  for (int64_t e = 0; e < nnz; ++e) ptr[e + 1] += ptr[e];
+  std::vector<int32_t> src(ptr[nnz]);
+  std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
+  for (int c = 0; c < n_cells; ++c)
+    for (int a = 0; a < per_r; ++a)
+      for (int b = 0; b < per_c; ++b) {
+        const int32_t e = epos[((size_t)c * per_r + a) * per_c + b];
+        const int64_t plane = plane_rc_swapped ? ((int64_t)b * per_r + a) : ((int64_t)a * per_c + b);
+        const int64_t off = plane * plane_stride * n_cells + c;
+        if (off > INT32_MAX) NSX_THROW(NSX_ERR_UNSUPPORTED, "mesh too large for int32 gather offsets");
+        src[fill[e]++] = (int32_t)off;
+      }
+  gm.n_out = nnz;
+  gm.n_src = (int64_t)src.size();
+  gm.ptr.upload(ptr, h->stream);
+  gm.src.upload(src, h->stream);
+}
+
+void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> &bptr, IluSchedule &s) {
+  const int nb = (int)bptr.size() - 1;
+  s.n_blocks = nb;
+  s.block_ptr_h = bptr;
+  s.max_rows = 0;
+  std::vector<int32_t> lev(g.n_rows, 0);
+  std::vector<int32_t> f_ptr{0}, f_rows, b_ptr{0}, b_rows, off_f(nb + 1, 0), off_b(nb + 1, 0);
+  f_rows.reserve(g.n_rows);
+  b_rows.reserve(g.n_rows);
+  s.max_levels = 0;
+  std::vector<std::vector<int32_t>> buckets;
+  for (int b = 0; b < nb; ++b) {
+    const int r0 = bptr[b], r1 = bptr[b + 1];
+    s.max_rows = std::max(s.max_rows, r1 - r0);
+    for (int pass = 0; pass < 2; ++pass) {
+      int nl = 0;
+      if (pass == 0) {
+        for (int i = r0; i < r1; ++i) {
+          int l = 0;
+          for (int k = g.rowptr[i]; k < g.rowptr[i + 1]; ++k) {
+            const int j = g.colind[k];
+            if (j >= i) break;
+            if (j >= r0) l = std::max(l, lev[j] + 1);
+          }
+          lev[i] = l;
+          nl = std::max(nl, l + 1);
+        }
+      } else {
+        for (int i = r1 - 1; i >= r0; --i) {
+          int l = 0;
+          for (int k = g.rowptr[i + 1] - 1; k >= g.rowptr[i]; --k) {
+            const int j = g.colind[k];
+            if (j <= i) break;
+            if (j < r1) l = std::max(l, lev[j] + 1);
+          }
+          lev[i] = l;
+          nl = std::max(nl, l + 1);
+        }
+      }
+      if (r1 == r0) nl = 0;
+      buckets.assign(nl, {});
+      for (int i = r0; i < r1; ++i) buckets[lev[i]].push_back(i);
+      auto &ptr = pass == 0 ? f_ptr : b_ptr;
+      auto &rows = pass == 0 ? f_rows : b_rows;
+      for (int l = 0; l < nl; ++l) {
+        rows.insert(rows.end(), buckets[l].begin(), buckets[l].end());
+        ptr.push_back((int32_t)rows.size());
+      }
+      (pass == 0 ? off_f : off_b)[b + 1] = (int32_t)ptr.size() - 1;
+      s.max_levels = std::max(s.max_levels, nl);
+    }
+  }
+  s.block_ptr.upload(bptr, h->stream);
+  s.fwd_lvl_ptr.upload(f_ptr, h->stream);
+  s.fwd_rows.upload(f_rows, h->stream);
+  s.bwd_lvl_ptr.upload(b_ptr, h->stream);
+  s.bwd_rows.upload(b_rows, h->stream);
+  s.blk_lvl_off.upload(off_f, h->stream);
+  s.blk_lvl_off_b.upload(off_b, h->stream);
+}
+
+void build_schur_graph(nsx_handle *h) {
+  // structural product of block(1,0) [P1 x P2] and block(0,1) [P2 x P1]
+  const Csr &B = h->gB.host, &G = h->gG.host;
+  Csr S;
+  S.n_rows = S.n_cols = h->NP;
+  S.rowptr.assign((size_t)h->NP + 1, 0);
+  std::vector<int32_t> mark(h->NP_loc, -1), cols;
+  for (int i = 0; i < h->NP; ++i) {
+    cols.clear();
+    for (int kb = B.rowptr[i]; kb < B.rowptr[i + 1]; ++kb) {
+      const int k = B.colind[kb];
+      if (k >= G.n_rows) continue;  // ghost P2 node: its G row lives on another rank
+      for (int kg = G.rowptr[k]; kg < G.rowptr[k + 1]; ++kg) {
+        const int j = G.colind[kg];
+        if (mark[j] != i) {
+          mark[j] = i;
+          cols.push_back(j);
+        }
+      }
+    }
+    std::sort(cols.begin(), cols.end());
+    S.colind.insert(S.colind.end(), cols.begin(), cols.end());
+    S.rowptr[i + 1] = (int32_t)S.colind.size();
+  }
+  h->gS.host = std::move(S);
+  upload_csr(h, h->gS, true);
+  h->vSchur.alloc(h->gS.nnz());
+  h->luS.alloc(h->gS.nnz());
+}
+
+static void default_ranks(nsx_handle *h) {
+  h->rank_u_h = {0, h->N2};
+  h->rank_p_h = {0, h->NP};
+  h->sblk_h.clear();
+}
+
+static void refresh_rank_products(nsx_handle *h) {
+  h->rank_u.upload(h->rank_u_h, h->stream);
+  h->dbar.alloc(h->rank_u_h.size() - 1);
+  setup_ilu_schedule(h, h->gA.host, h->rank_u_h, h->schedF);
+  setup_ilu_schedule(h, h->gS.host, h->sblk_h.empty() ? h->rank_p_h : h->sblk_h, h->schedS);
+  h->prec_ready = false;
+}
+
+}  // namespace nsx
+
+#define NSX_TRY(h_) try {
+#define NSX_CATCH(h_)                                      \
+  }                                                        \
+  catch (const nsx::Error &e) {                            \
+    (h_)->err = e.msg;                                     \
+    return e.code;                                         \
+  }                                                        \
+  catch (const std::exception &e) {                        \
+    (h_)->err = e.what();                                  \
+    return NSX_ERR_ARG;                                    \
+  }                                                        \
+  return NSX_OK;
+
+extern "C" {
+
+const char *nsx_version(void) { return "nsx 0.1 (gfx950)"; }
+
+const char *nsx_last_error(const nsx_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int nsx_create(const nsx_params *p, nsx_handle **out) {
+  if (!p || !out) return NSX_ERR_ARG;
+  *out = nullptr;
+  if (p->dim != 2 && p->dim != 3) {
+    g_create_error = "dim must be 2 or 3";
+    return NSX_ERR_ARG;
+  }
+  if (!(p->nu > 0) || !(p->deltat > 0)) {
+    g_create_error = "nu and deltat must be positive";
+    return NSX_ERR_ARG;
+  }
+  auto *h = new nsx_handle;
+  h->prm = *p;
+  h->dim = p->dim;
+  try {
+    int ndev = 0;
+    HIP_CHECK(hipGetDeviceCount(&ndev));
+    if (ndev < 1) NSX_THROW(NSX_ERR_HIP, "no HIP device visible: libnsx has no CPU fallback");
+    if (p->device < 0 || p->device >= ndev) NSX_THROW(NSX_ERR_ARG, "device %d out of range (%d visible)", p->device, ndev);
+    HIP_CHECK(hipSetDevice(p->device));
+    HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->scal.alloc(N_SLOTS);
+    h->scal.zero(h->stream);
+    h->red_partial.alloc((size_t)N_SLOTS * 1024);
+    HIP_CHECK(hipHostMalloc((void **)&h->scal_host, N_SLOTS * sizeof(double), hipHostMallocDefault));
+  } catch (const nsx::Error &e) {
+    g_create_error = e.msg;
+    delete h;
+    return e.code;
+  }
+  *out = h;
+  return NSX_OK;
+}
+
+int nsx_destroy(nsx_handle *h) {
+  if (!h) return NSX_OK;
+  (void)hipSetDevice(h->prm.device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  nsx::comm_destroy(h);
+  for (auto &kv : h->prof)
+    for (auto &ev : kv.second.pending) {
+      (void)hipEventDestroy(ev.first);
+      (void)hipEventDestroy(ev.second);
+    }
+  for (auto *b : h->pool) delete b;
+  if (h->scal_host) (void)hipHostFree(h->scal_host);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return NSX_OK;
+}
+
+int nsx_set_tables(nsx_handle *h, int n_q, int n_p2, int n_p1, const double *N2, const double *dN2, const double *N1,
+                   const double *w) {
+  NSX_TRY(h)
+  if (!N2 || !dN2 || !N1 || !w || n_q < 1) NSX_THROW(NSX_ERR_ARG, "null table / n_q < 1");
+  const int dim = h->dim;
+  if (n_p1 != dim + 1 || n_p2 != (dim == 2 ? 6 : 10))
+    NSX_THROW(NSX_ERR_UNSUPPORTED, "only Taylor-Hood P2/P1 on simplices (n_p2=%d n_p1=%d for dim=%d)", dim == 2 ? 6 : 10, dim + 1, dim);
+  HIP_CHECK(hipSetDevice(h->prm.device));
+  h->n_q = n_q;
+  h->np2 = n_p2;
+  h->np1 = n_p1;
+  h->N2_h.assign(N2, N2 + (size_t)n_q * n_p2);
+  h->dN2_h.assign(dN2, dN2 + (size_t)n_q * n_p2 * dim);
+  h->N1_h.assign(N1, N1 + (size_t)n_q * n_p1);
+  h->w_h.assign(w, w + n_q);
+  h->tab_N2.upload(h->N2_h, h->stream);
+  h->tab_dN2.upload(h->dN2_h, h->stream);
+  h->tab_N1.upload(h->N1_h, h->stream);
+  h->tab_w.upload(h->w_h, h->stream);
+  {
+    std::vector<double> NT((size_t)n_q * n_p2), dNT((size_t)n_q * n_p2 * dim);
+    for (int q = 0; q < n_q; ++q)
+      for (int a = 0; a < n_p2; ++a) {
+        NT[(size_t)a * n_q + q] = N2[(size_t)q * n_p2 + a];
+        for (int k = 0; k < dim; ++k) dNT[((size_t)a * n_q + q) * dim + k] = dN2[((size_t)q * n_p2 + a) * dim + k];
+      }
+    h->tab_N2T.upload(NT, h->stream);
+    h->tab_dN2T.upload(dNT, h->stream);
+  }
+  h->have_tables = true;
+  NSX_CATCH(h)
+}
+
+int nsx_set_mesh(nsx_handle *h, int n_cells, int dpc, const int32_t *cell_dofs, const double *cell_coords, int n_u, int n_p) {
+  NSX_TRY(h)
+  if (!h->have_tables) NSX_THROW(NSX_ERR_ARG, "nsx_set_tables must be called before nsx_set_mesh");
+  if (!cell_dofs || !cell_coords || n_cells < 1) NSX_THROW(NSX_ERR_ARG, "empty mesh");
+  HIP_CHECK(hipSetDevice(h->prm.device));
+  const int dim = h->dim, nv = dim + 1, nl = dim == 2 ? 3 : 6, np2 = h->np2, np1 = h->np1;
+  if (dpc != nv * (dim + 1) + nl * dim) NSX_THROW(NSX_ERR_ARG, "dofs_per_cell %d does not match FESystem(P2^%d,P1)", dpc, dim);
+  if (n_u % dim) NSX_THROW(NSX_ERR_ARG, "n_u not a multiple of dim");
+  h->dpc = dpc;
+  h->n_cells = n_cells;
+  h->n_u = n_u;
+  h->n_p = n_p;
+  h->N2 = h->N2_loc = n_u / dim;
+  h->NP = h->NP_loc = n_p;
+  // scalar connectivity from the FESystem dof table
+  h->cell_n2_h.resize((size_t)n_cells * np2);
+  h->cell_n1_h.resize((size_t)n_cells * np1);
+  for (int c = 0; c < n_cells; ++c) {
+    const int32_t *cd = cell_dofs + (size_t)c * dpc;
+    for (int a = 0; a < np2; ++a) {
+      const int base = a < nv ? (dim + 1) * a : nv * (dim + 1) + dim * (a - nv);
+      const int32_t d0 = cd[base];
+      if (d0 < 0 || d0 >= n_u || d0 % dim) NSX_THROW(NSX_ERR_ARG, "cell %d: velocity dof %d breaks the dim*node+c numbering contract", c, d0);
+      for (int k = 1; k < dim; ++k)
+        if (cd[base + k] != d0 + k) NSX_THROW(NSX_ERR_ARG, "cell %d: velocity components of one node are not consecutive", c);
+      h->cell_n2_h[(size_t)c * np2 + a] = d0 / dim;
+    }
+    for (int v = 0; v < nv; ++v) {
+      const int32_t d = cd[(dim + 1) * v + dim] - n_u;
+      if (d < 0 || d >= n_p) NSX_THROW(NSX_ERR_ARG, "cell %d: pressure dof out of range", c);
+      h->cell_n1_h[(size_t)c * np1 + v] = d;
+    }
+  }
+  // graphs (reference NavierStokes3D.cpp:109-124, pressure mass :127-142)
+  const int32_t *c2 = h->cell_n2_h.data(), *c1 = h->cell_n1_h.data();
+  h->gA.host = build_graph(n_cells, np2, c2, h->N2, np2, c2, h->N2);
+  h->gG.host = build_graph(n_cells, np2, c2, h->N2, np1, c1, h->NP);
+  h->gB.host = build_graph(n_cells, np1, c1, h->NP, np2, c2, h->N2);
+  h->gPM.host = build_graph(n_cells, np1, c1, h->NP, np1, c1, h->NP);
+  upload_csr(h, h->gA, true);
+  upload_csr(h, h->gG, false);
+  upload_csr(h, h->gB, false);
+  upload_csr(h, h->gPM, true);
+  // SoA cell tables + geometry
+  {
+    std::vector<int32_t> t2((size_t)n_cells * np2), t1((size_t)n_cells * np1);
+    for (int c = 0; c < n_cells; ++c) {
+      for (int a = 0; a < np2; ++a) t2[(size_t)a * n_cells + c] = c2[(size_t)c * np2 + a];
+      for (int v = 0; v < np1; ++v) t1[(size_t)v * n_cells + c] = c1[(size_t)c * np1 + v];
+    }
+    h->cell_n2.upload(t2, h->stream);
+    h->cell_n1.upload(t1, h->stream);
+    const int ng = dim * dim + 1;
+    std::vector<double> geo((size_t)ng * n_cells);
+    for (int c = 0; c < n_cells; ++c) {
+      const double *X = cell_coords + (size_t)c * nv * dim;
+      double J[3][3] = {{0}}, Ji[3][3] = {{0}}, det;
+      for (int d = 0; d < dim; ++d)
+        for (int k = 0; k < dim; ++k) J[d][k] = X[(k + 1) * dim + d] - X[d];
+      if (dim == 2) {
+        det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+        Ji[0][0] = J[1][1] / det;
+        Ji[0][1] = -J[0][1] / det;
+        Ji[1][0] = -J[1][0] / det;
+        Ji[1][1] = J[0][0] / det;
+      } else {
+        det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) - J[0][1] * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) +
+              J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+        Ji[0][0] = (J[1][1] * J[2][2] - J[1][2] * J[2][1]) / det;
+        Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) / det;
+        Ji[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) / det;
+        Ji[1][0] = (J[1][2] * J[2][0] - J[1][0] * J[2][2]) / det;
+        Ji[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) / det;
+        Ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) / det;
+        Ji[2][0] = (J[1][0] * J[2][1] - J[1][1] * J[2][0]) / det;
+        Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) / det;
+        Ji[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) / det;
+      }
+      if (!(std::fabs(det) > 0)) NSX_THROW(NSX_ERR_ARG, "cell %d is degenerate", c);
+      for (int k = 0; k < dim; ++k)
+        for (int d = 0; d < dim; ++d) geo[(size_t)(k * dim + d) * n_cells + c] = Ji[k][d];
+      geo[(size_t)(dim * dim) * n_cells + c] = std::fabs(det);
+    }
+    h->geo.upload(geo, h->stream);
+  }
+  // gather maps (cell order ascending inside every list -> same summation order as the reference's cell loop)
+  build_gather(h, h->gA.host, n_cells, np2, c2, np2, c2, 1, false, h->gmA);
+  build_gather(h, h->gG.host, n_cells, np2, c2, np1, c1, dim, false, h->gmG);   // planes (a*np1+v)*dim
+  build_gather(h, h->gB.host, n_cells, np1, c1, np2, c2, dim, true, h->gmB);    // same planes, indexed (v,a)
+  build_gather(h, h->gPM.host, n_cells, np1, c1, np1, c1, 1, false, h->gmPM);
+  const size_t planes = std::max((size_t)np2 * np2, (size_t)np2 * np1 * dim);
+  h->cellbuf.alloc(planes * n_cells);
+  const int64_t nA = h->gA.nnz();
+  h->vS0.alloc(nA);
+  h->vMass.alloc(nA);
+  h->vStiff.alloc(nA);
+  h->vConv.alloc(nA);
+  h->vF.alloc(nA);
+  h->luF.alloc(nA);
+  h->vG.alloc(h->gG.nnz() * dim);
+  h->vB.alloc(h->gB.nnz() * dim);
+  h->vPM.alloc(h->gPM.nnz());
+  const size_t n = (size_t)n_u + n_p;
+  for (auto *v : {&h->sol, &h->sol_owned, &h->prev_sol, &h->rhs}) {
+    v->alloc(n);
+    v->zero(h->stream);
+  }
+  for (auto *v : {&h->diag_D, &h->diag_D_inv, &h->neg_diag_D_inv, &h->lump_M, &h->schur_w, &h->dirmask}) v->alloc(n_u);
+  build_schur_graph(h);
+  default_ranks(h);
+  refresh_rank_products(h);
+  HIP_CHECK(hipStreamSynchronize(h->stream));
+  h->have_mesh = true;
+  h->assembled = false;
+  NSX_CATCH(h)
+}
+
+int nsx_set_ranks(nsx_handle *h, int n_ranks, const int32_t *u_ptr, const int32_t *p_ptr) {
+  NSX_TRY(h)
+  if (!h->have_mesh) NSX_THROW(NSX_ERR_ARG, "nsx_set_mesh first");
+  if (n_ranks < 1 || !u_ptr || !p_ptr) NSX_THROW(NSX_ERR_ARG, "bad rank table");
+  if (u_ptr[0] != 0 || p_ptr[0] != 0 || u_ptr[n_ranks] != h->N2 || p_ptr[n_ranks] != h->NP)
+    NSX_THROW(NSX_ERR_ARG, "rank ranges must cover [0,N2) and [0,NP)");
+  for (int r = 0; r < n_ranks; ++r)
+    if (u_ptr[r + 1] < u_ptr[r] || p_ptr[r + 1] < p_ptr[r]) NSX_THROW(NSX_ERR_ARG, "rank ranges must be ascending");
+  HIP_CHECK(hipSetDevice(h->prm.device));
+  h->rank_u_h.assign(u_ptr, u_ptr + n_ranks + 1);
+  h->rank_p_h.assign(p_ptr, p_ptr + n_ranks + 1);
+  refresh_rank_products(h);
+  NSX_CATCH(h)
+}
+
+int nsx_set_schur_blocks(nsx_handle *h, int n_blocks, const int32_t *p_ptr) {
+  NSX_TRY(h)
+  if (!h->have_mesh) NSX_THROW(NSX_ERR_ARG, "nsx_set_mesh first");
+  if (n_blocks < 1 || !p_ptr || p_ptr[0] != 0 || p_ptr[n_blocks] != h->NP) NSX_THROW(NSX_ERR_ARG, "bad Schur block table");
+  HIP_CHECK(hipSetDevice(h->prm.device));
+  h->sblk_h.assign(p_ptr, p_ptr + n_blocks + 1);
+  refresh_rank_products(h);
+  NSX_CATCH(h)
+}
+
+// ---- state
+static int vec_io(nsx_handle *h, nsx::DevBuf<double> &v, double *out, const double *in) {
+  NSX_TRY(h)
+  if (!h->have_mesh) NSX_THROW(NSX_ERR_ARG, "nsx_set_mesh first");
+  HIP_CHECK(hipSetDevice(h->prm.device));
+  const size_t n = (size_t)h->n_u + h->n_p;
+  if (in) {
+    HIP_CHECK(hipMemcpyAsync(v.p, in, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+  } else {
+    if (!out) NSX_THROW(NSX_ERR_ARG, "null output");
+    v.download(out, n, h->stream);
+  }
+  NSX_CATCH(h)
+}
+
+int nsx_set_solution(nsx_handle *h, const double *s) {
+  if (!s) return NSX_ERR_ARG;
+  int rc = vec_io(h, h->sol_owned, nullptr, s);
+  if (rc) return rc;
+  return vec_io(h, h->sol, nullptr, s);
+}
+int nsx_get_solution(nsx_handle *h, double *s) { return vec_io(h, h->sol_owned, s, nullptr); }
+int nsx_get_solution_ghosted(nsx_handle *h, double *s) { return vec_io(h, h->sol, s, nullptr); }
+int nsx_get_rhs(nsx_handle *h, double *s) { return vec_io(h, h->rhs, s, nullptr); }
+int nsx_set_rhs(nsx_handle *h, const double *s) { return s ? vec_io(h, h->rhs, nullptr, s) : NSX_ERR_ARG; }
+
+// ---- exports
+int nsx_scalar_graph_nnz(nsx_handle *h, int which, int64_t *nnz) {
+  if (!h || !nnz || !h->have_mesh || which < 0 || which > 1) return NSX_ERR_ARG;
+  *nnz = which == 0 ? h->gA.nnz() : h->gS.nnz();
+  return NSX_OK;
+}
+int nsx_scalar_graph(nsx_handle *h, int which, int32_t *rowptr, int32_t *colind) {
+  if (!h || !rowptr || !colind || !h->have_mesh || which < 0 || which > 1) return NSX_ERR_ARG;
+  const nsx::Csr &g = which == 0 ? h->gA.host : h->gS.host;
+  std::copy(g.rowptr.begin(), g.rowptr.end(), rowptr);
+  std::copy(g.colind.begin(), g.colind.end(), colind);
+  return NSX_OK;
+}
+int nsx_ilu_get(nsx_handle *h, int which, double *values) {
+  NSX_TRY(h)
+  if (!values || which < 0 || which > 1 || !h->prec_ready) NSX_THROW(NSX_ERR_ARG, "no factors: call nsx_prec_initialize first");
+  HIP_CHECK(hipSetDevice(h->prm.device));
+  (which == 0 ? h->luF : h->luS).download(values, which == 0 ? h->gA.nnz() : h->gS.nnz(), h->stream);
+  NSX_CATCH(h)
+}
+int nsx_schur_nnz(nsx_handle *h, int64_t *nnz) { return nsx_scalar_graph_nnz(h, 1, nnz); }
+int nsx_schur_get(nsx_handle *h, int32_t *rowptr, int32_t *colind, double *values) {
+  NSX_TRY(h)
+  if (!h->prec_ready) NSX_THROW(NSX_ERR_ARG, "no Schur matrix: call nsx_prec_initialize first");
+  HIP_CHECK(hipSetDevice(h->prm.device));
+  int rc = nsx_scalar_graph(h, 1, rowptr, colind);
+  if (rc) NSX_THROW(rc, "bad arguments");
+  h->vSchur.download(values, h->gS.nnz(), h->stream);
+  NSX_CATCH(h)
+}
+
+int nsx_export_block(nsx_handle *h, int which, int block, int n_rows, const int32_t *rowptr, const int32_t *colind, double *values) {
+  NSX_TRY(h)
+  if (!h->assembled) NSX_THROW(NSX_ERR_ARG, "nothing assembled yet");
+  if (!rowptr || !colind || !values) NSX_THROW(NSX_ERR_ARG, "null graph");
+  HIP_CHECK(hipSetDevice(h->prm.device));
+  const int dim = h->dim;
+  const int64_t nnz = rowptr[n_rows];
+  std::fill(values, values + nnz, 0.0);
+  if (which == 4) {
+    if (block != 3 || n_rows != h->n_p) NSX_THROW(NSX_ERR_ARG, "pressure_mass lives in block (1,1)");
+    std::vector<double> v(h->gPM.nnz());
+    h->vPM.download(v.data(), v.size(), h->stream);
+    for (int i = 0; i < n_rows; ++i)
+      for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+        const int e = nsx::find_in_row(h->gPM.host, i, colind[k]);
+        if (e >= 0) values[k] = v[e];
+      }
+  } else if (block == 0) {
+    if (n_rows != h->n_u) NSX_THROW(NSX_ERR_ARG, "block (0,0) has n_u rows");
+    nsx::DevBuf<double> *src = which == 0 ? &h->vF : which == 1 ? &h->vMass : which == 2 ? &h->vConv : which == 3 ? &h->vStiff : nullptr;
+    if (!src) NSX_THROW(NSX_ERR_ARG, "bad matrix id");
+    std::vector<double> v(h->gA.nnz());
+    src->download(v.data(), v.size(), h->stream);
+    for (int i = 0; i < n_rows; ++i) {
+      const int node = i / dim, c = i % dim;
+      for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+        if (colind[k] % dim != c) continue;  // cross-component slots are structural zeros in the reference
+        const int e = nsx::find_in_row(h->gA.host, node, colind[k] / dim);
+        if (e >= 0) values[k] = v[e];
+      }
+    }
+  } else if (block == 1 || block == 2) {
+    if (which != 0) return NSX_OK;  // only system_matrix carries the B blocks (mass/convection/stiffness store zeros there)
+    const bool isG = block == 1;
+    if (n_rows != (isG ? h->n_u : h->n_p)) NSX_THROW(NSX_ERR_ARG, "row count does not match the block");
+    const nsx::DevCsr &g = isG ? h->gG : h->gB;
+    std::vector<double> v(g.nnz() * dim);
+    (isG ? h->vG : h->vB).download(v.data(), v.size(), h->stream);
+    for (int i = 0; i < n_rows; ++i)
+      for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+        if (isG) {
+          const int e = nsx::find_in_row(g.host, i / dim, colind[k]);
+          if (e >= 0) values[k] = v[(size_t)e * dim + i % dim];
+        } else {
+          const int e = nsx::find_in_row(g.host, i, colind[k] / dim);
+          if (e >= 0) values[k] = v[(size_t)e * dim + colind[k] % dim];
+        }
+      }
+  } else {
+    NSX_THROW(NSX_ERR_ARG, "bad block id");
+  }
+  NSX_CATCH(h)
+}
+
+// ---- profiling
+int nsx_profile_enable(nsx_handle *h, int on) {
+  if (!h) return NSX_ERR_ARG;
+  h->prof_on = on != 0;
+  return NSX_OK;
+}
+static void prof_collect(nsx_handle *h) {
+  (void)hipSetDevice(h->prm.device);
+  (void)hipStreamSynchronize(h->stream);
+  for (auto &kv : h->prof) {
+    for (auto &ev : kv.second.pending) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) kv.second.ms += ms;
+      (void)hipEventDestroy(ev.first);
+      (void)hipEventDestroy(ev.second);
+    }
+    kv.second.pending.clear();
+  }
+}
+int nsx_profile_reset(nsx_handle *h) {
+  if (!h) return NSX_ERR_ARG;
+  prof_collect(h);
+  h->prof.clear();
+  return NSX_OK;
+}
+int nsx_profile_count(nsx_handle *h) {
+  if (!h) return NSX_ERR_ARG;
+  prof_collect(h);
+  h->prof_names.clear();
+  for (auto &kv : h->prof) h->prof_names.push_back(kv.first);
+  return (int)h->prof_names.size();
+}
+int nsx_profile_get(nsx_handle *h, int i, const char **name, int64_t *launches, double *total_ms, double *bytes) {
+  if (!h || i < 0 || i >= (int)h->prof_names.size()) return NSX_ERR_ARG;
+  const auto &e = h->prof[h->prof_names[i]];
+  if (name) *name = h->prof_names[i].c_str();
+  if (launches) *launches = e.launches;
+  if (total_ms) *total_ms = e.ms;
+  if (bytes) *bytes = e.bytes;
+  return NSX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,425 @@
+// nsx_solve.hip — Krylov drivers and the four block preconditioners.
+//
+//   NavierStokes::solve_time_step          reference Navier-Stokes/src/NavierStokes3D.cpp:546-640
+//   PreconditionSIMPLE / aSIMPLE / Yosida / aYosida (initialize + vmult)
+//                                           reference Navier-Stokes/include/Preconditioners.hpp:118-217, 220-329, 332-423, 427-534
+//   SolverGMRES / SolverCG                  deal.II templates the reference instantiates (NS3D.cpp:554; Prec.hpp:159,180,272,288,372,389,404,501):
+//                                           left-preconditioned restarted GMRES (30 temporary vectors => restart 28, modified Gram-Schmidt
+//                                           with the Kelley re-orthogonalisation test, stopping on the preconditioned residual) and
+//                                           preconditioned CG stopping on the true residual; restated from the published deal.II 9.3-9.5 algorithms.
+//
+// Host-driven control flow, device-resident vectors and scalars: one host synchronisation per Krylov iteration
+// (the Hessenberg column / residual norm), none inside the Gram-Schmidt sweep.
+#include <chrono>
+#include <cmath>
+#include <functional>
+#include <memory>
+
+#include "nsx_internal.hpp"
+
+namespace nsx {
+
+void cg_update(nsx_handle *h, int n, double *x, const double *d, double *g, const double *hv, int gh_slot, int dh_slot, int res_slot);
+void cg_direction(nsx_handle *h, int n, double *d, const double *hv, int num_slot, int den_slot);
+void v_reciprocal(nsx_handle *h, int n, double *d, const double *s, double num);
+
+// ---- pooled temporary vectors (TrilinosWrappers::MPI::Vector temporaries of Prec.hpp:168-171,375-378 and the solvers' own)
+struct Tmp {
+  nsx_handle *h;
+  DevBuf<double> *b;
+  Tmp(nsx_handle *h_, size_t n) : h(h_), b(nullptr) {
+    for (size_t i = 0; i < h->pool.size(); ++i)
+      if (h->pool[i]->n >= n) {
+        b = h->pool[i];
+        h->pool.erase(h->pool.begin() + i);
+        break;
+      }
+    if (!b) {
+      b = new DevBuf<double>();
+      b->alloc(n);
+    }
+  }
+  ~Tmp() { h->pool.push_back(b); }
+  Tmp(const Tmp &) = delete;
+  double *p() const { return b->p; }
+};
+
+using Op = std::function<void(double *dst, const double *src)>;
+
+struct SolveResult {
+  int status;  // 0 success, 1 failure
+  int steps;
+  double last;
+};
+
+static int sc_check(int step, double value, double tol, int maxsteps) {  // SolverControl::check: 0 iterate, 1 success, 2 failure
+  if (value <= tol) return 1;
+  if (step >= maxsteps || std::isnan(value)) return 2;
+  return 0;
+}
+
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+constexpr int N_TMP = 30;  // SolverGMRES::AdditionalData::max_n_tmp_vectors
+enum { S_H = 8 /* 8..8+N_TMP */, S_NRM = 40, S_H2 = 41 /* re-orthogonalisation coefficients 41..41+N_TMP */, S_GH = 2, S_DH = 3, S_RES = 4, S_GH2 = 5, S_T = 6 };
+
+// SolverGMRES<VectorType>::solve (left preconditioning, default residual).
+static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b, const Op &P, int n, double tol, int maxiter) {
+  SolveResult res{1, 0, 0.0};
+  std::vector<std::unique_ptr<Tmp>> tmp(N_TMP);
+  auto vec = [&](int i) -> double * {
+    if (!tmp[i]) {
+      tmp[i] = std::make_unique<Tmp>(h, n);
+      v_zero(h, n, tmp[i]->p());  // a freshly created Epetra vector is zero
+    }
+    return tmp[i]->p();
+  };
+  double H[N_TMP][N_TMP - 1];
+  double gamma[N_TMP], ci[N_TMP - 1], si[N_TMP - 1], hh[N_TMP + 1], h2[N_TMP + 1];
+  int accumulated = 0, state = 0, dim = 0;
+  bool re_orth = false;
+  double *v = vec(0), *p = vec(N_TMP - 1);
+  do {
+    A(p, x);
+    v_sadd(h, n, p, -1., 1., b);
+    P(v, p);
+    v_dot(h, n, v, v, S_NRM);
+    double rho = std::sqrt(read_scalar(h, S_NRM));
+    res.last = rho;
+    state = sc_check(accumulated, rho, tol, maxiter);
+    if (state != 0) break;
+    gamma[0] = rho;
+    v_scale(h, n, v, 1. / rho);
+    dim = 0;
+    for (int inner = 0; inner < N_TMP - 2 && state == 0; ++inner) {
+      ++accumulated;
+      double *vv = vec(inner + 1);
+      A(p, vec(inner));
+      P(vv, p);
+      dim = inner + 1;
+      // modified Gram-Schmidt, h(i) = vv . v_i after removing the previous components (add_and_dot chain)
+      const bool consider = !re_orth && (inner % 5 == 4);
+      if (consider) v_dot(h, n, vv, vv, S_NRM);
+      v_dot(h, n, vv, vec(0), S_H);
+      for (int i = 1; i < dim; ++i) v_add_and_dot(h, n, vv, -1.0, S_H + i - 1, vec(i - 1), vec(i), S_H + i);
+      v_add_and_dot(h, n, vv, -1.0, S_H + dim - 1, vec(dim - 1), vv, S_H + dim);
+      read_scalars(h, S_H, dim + 1, hh);
+      double s = std::sqrt(hh[dim]);
+      if (consider) {
+        const double norm_vv_start = std::sqrt(read_scalar(h, S_NRM));
+        if (!(s > 10. * norm_vv_start * std::sqrt(2.220446049250313e-16))) re_orth = true;
+      }
+      if (re_orth) {
+        v_dot(h, n, vv, vec(0), S_H2);
+        for (int i = 1; i < dim; ++i) v_add_and_dot(h, n, vv, -1.0, S_H2 + i - 1, vec(i - 1), vec(i), S_H2 + i);
+        v_add_and_dot(h, n, vv, -1.0, S_H2 + dim - 1, vec(dim - 1), vv, S_H2 + dim);
+        read_scalars(h, S_H2, dim + 1, h2);
+        for (int i = 0; i < dim; ++i) hh[i] += h2[i];
+        s = std::sqrt(h2[dim]);
+      }
+      hh[inner + 1] = s;
+      if (s != 0) v_scale(h, n, vv, 1. / s);
+      // givens_rotation(h, gamma, ci, si, inner)
+      for (int i = 0; i < inner; ++i) {
+        const double sn = si[i], cs = ci[i], dummy = hh[i];
+        hh[i] = cs * dummy + sn * hh[i + 1];
+        hh[i + 1] = -sn * dummy + cs * hh[i + 1];
+      }
+      const double r = 1. / std::sqrt(hh[inner] * hh[inner] + hh[inner + 1] * hh[inner + 1]);
+      si[inner] = hh[inner + 1] * r;
+      ci[inner] = hh[inner] * r;
+      hh[inner] = ci[inner] * hh[inner] + si[inner] * hh[inner + 1];
+      gamma[inner + 1] = -si[inner] * gamma[inner];
+      gamma[inner] *= ci[inner];
+      for (int i = 0; i < dim; ++i) H[i][inner] = hh[i];
+      rho = std::fabs(gamma[dim]);
+      res.last = rho;
+      state = sc_check(accumulated, rho, tol, maxiter);
+    }
+    double y[N_TMP];
+    for (int i = dim - 1; i >= 0; --i) {  // H1.backward(h, gamma)
+      double s = gamma[i];
+      for (int j = i + 1; j < dim; ++j) s -= H[i][j] * y[j];
+      y[i] = s / H[i][i];
+    }
+    double *vs[N_TMP];
+    for (int i = 0; i < dim; ++i) vs[i] = vec(i);
+    v_axpy_multi(h, n, x, dim, vs, y);
+  } while (state == 0);
+  res.status = state == 1 ? 0 : 1;
+  res.steps = accumulated;
+  return res;
+}
+
+// SolverCG<VectorType>::solve with a preconditioner.
+static SolveResult cg(nsx_handle *h, const Op &A, double *x, const double *b, const Op &P, int n, double tol, int maxiter) {
+  SolveResult res{1, 0, 0.0};
+  Tmp g(h, n), d(h, n), hv(h, n);
+  int it = 0;
+  // g = A x - b.  deal.II short-cuts to g = -b when x.all_zero(); A*0 - b gives the identical vector, so no device-side test is needed.
+  A(g.p(), x);
+  v_add(h, n, g.p(), -1., b);
+  v_dot(h, n, g.p(), g.p(), S_RES);
+  double r = std::sqrt(read_scalar(h, S_RES));
+  res.last = r;
+  int conv = sc_check(0, r, tol, maxiter);
+  if (conv == 0) {
+    P(hv.p(), g.p());
+    v_copy(h, n, d.p(), hv.p());
+    v_scale(h, n, d.p(), -1.);
+    int gh = S_GH, gh_new = S_GH2;  // ping-pong slots for (g.h) of the current / next iteration
+    v_dot(h, n, g.p(), hv.p(), gh);
+    while (conv == 0) {
+      it++;
+      A(hv.p(), d.p());
+      v_dot(h, n, d.p(), hv.p(), S_DH);
+      cg_update(h, n, x, d.p(), g.p(), hv.p(), gh, S_DH, S_RES);  // alpha = gh / (d.h); x += alpha d; g += alpha h; res = |g|
+      r = std::sqrt(std::fabs(read_scalar(h, S_RES)));
+      res.last = r;
+      conv = sc_check(it, r, tol, maxiter);
+      if (conv != 0) break;
+      P(hv.p(), g.p());
+      v_dot(h, n, g.p(), hv.p(), gh_new);
+      cg_direction(h, n, d.p(), hv.p(), gh_new, gh);  // beta = gh_new / gh_old ; d = beta d - h
+      std::swap(gh, gh_new);
+    }
+  }
+  res.status = conv == 1 ? 0 : 1;
+  res.steps = it;
+  return res;
+}
+
+static double norm2(nsx_handle *h, int n, const double *v) {
+  v_dot(h, n, v, v, S_T);
+  return std::sqrt(read_scalar(h, S_T));
+}
+
+// ------------------------------------------------------------------ preconditioners
+void prec_initialize(nsx_handle *h, int type) {
+  if (!h->assembled) NSX_THROW(NSX_ERR_ARG, "assemble before initialising a preconditioner");
+  HIP_CHECK(hipSetDevice(h->prm.device));
+  const int n_u = h->n_u;
+  const double *V = nullptr;
+  if (type == NSX_PREC_YOSIDA) {  // Prec.hpp:350-355: D = diag(mass_matrix) (= M/dt)
+    extract_diag(h, h->gA, h->vMass.p, h->diag_D.p);
+  } else if (type == NSX_PREC_SIMPLE || type == NSX_PREC_ASIMPLE || type == NSX_PREC_AYOSIDA) {  // Prec.hpp:135-140,239-245,447-452
+    extract_diag(h, h->gA, h->vF.p, h->diag_D.p);
+  } else {
+    NSX_THROW(NSX_ERR_ARG, "Invalid preconditioner type");  // std::runtime_error of NS3D.cpp:633
+  }
+  // diag_D_inv = 1/D, neg_diag_D_inv = -1/D
+  v_reciprocal(h, n_u, h->diag_D_inv.p, h->diag_D.p, 1.0);
+  v_reciprocal(h, n_u, h->neg_diag_D_inv.p, h->diag_D.p, -1.0);
+  V = h->neg_diag_D_inv.p;
+  if (type == NSX_PREC_AYOSIDA) {  // Prec.hpp:456-465: lump_M = -1 / sum_j |M_ij|
+    abs_rowsum(h, h->gA, h->vMass.p, h->lump_M.p);
+    v_reciprocal(h, n_u, h->lump_M.p, h->lump_M.p, -1.0);
+    V = h->lump_M.p;
+  }
+  // negative_S = B * diag(V) * B_T with B_T = -B^T (Dirichlet rows cleared): weights w = -V * mask
+  v_copy(h, n_u, h->schur_w.p, V);
+  v_scale_vec(h, n_u, h->schur_w.p, h->dirmask.p);
+  v_scale(h, n_u, h->schur_w.p, -1.0);
+  schur_numeric(h, h->schur_w.p);
+  // preconditioner_F.initialize(*F); preconditioner_S.initialize(negative_S)   (Prec.hpp:147-148,250-251,361-362,470-471)
+  ilu_factor(h, h->gA, h->schedF, h->vF.p, h->luF.p, "ilu_factor_F");
+  ilu_factor(h, h->gS, h->schedS, h->vSchur.p, h->luS.p, "ilu_factor_S");
+  h->prec_ready = true;
+}
+
+static void count(nsx_solve_stats *st, bool F, const SolveResult &r) {
+  if (!st) return;
+  if (F) {
+    st->inner_F_iterations += r.steps;
+    st->n_F_solves++;
+  } else {
+    st->inner_S_iterations += r.steps;
+    st->n_S_solves++;
+  }
+  if (r.status) st->status = 2;
+}
+
+void prec_vmult(nsx_handle *h, int type, double tol, int maxit, double *dst, const double *src, nsx_solve_stats *st) {
+  if (!h->prec_ready) NSX_THROW(NSX_ERR_ARG, "preconditioner not initialised");
+  const int n_u = h->n_u, n_p = h->n_p, dim = h->dim;
+  const double *src_u = src, *src_p = src + n_u;
+  double *dst_u = dst, *dst_p = dst + n_u;
+  Op Fm = [h](double *d, const double *s) { spmv_F(h, h->vF.p, s, d); };
+  Op Sm = [h](double *d, const double *s) { spmv_S(h, s, d); };
+  Op PF = [h, dim](double *d, const double *s) { ilu_solve(h, h->gA, h->schedF, h->luF.p, s, d, dim, "ilu_solve_F"); };
+  Op PS = [h](double *d, const double *s) { ilu_solve(h, h->gS, h->schedS, h->luS.p, s, d, 1, "ilu_solve_S"); };
+
+  if (type == NSX_PREC_YOSIDA) {  // Prec.hpp:365-408
+    Tmp yu(h, n_u), yp(h, n_p), tmp(h, n_p), tmp2(h, n_u), res(h, n_u);
+    v_copy(h, n_u, yu.p(), src_u);                                                            // :375
+    v_copy(h, n_p, yp.p(), src_p);                                                            // :376
+    count(st, true, gmres(h, Fm, yu.p(), src_u, PF, n_u, tol * norm2(h, n_u, src_u), maxit)); // :371-382
+    spmv_B(h, yu.p(), tmp.p());                                                               // :385
+    v_add(h, n_p, tmp.p(), -1.0, src_p);                                                      // :386
+    count(st, false, cg(h, Sm, yp.p(), tmp.p(), PS, n_p, tol * norm2(h, n_p, tmp.p()), maxit));  // :388-390
+    v_copy(h, n_p, dst_p, yp.p());                                                            // :394
+    spmv_G(h, dst_p, tmp2.p(), false);                                                        // :398
+    v_zero(h, n_u, res.p());                                                                  // :401
+    v_copy(h, n_u, dst_u, yu.p());                                                            // :402
+    count(st, true, gmres(h, Fm, res.p(), tmp2.p(), PF, n_u, tol * norm2(h, n_u, tmp2.p()), maxit));  // :403-405
+    v_sadd(h, n_u, dst_u, -1., 1., res.p());  // dst.block(0).sadd(-1,res): dst = -dst + res            :406
+  } else if (type == NSX_PREC_SIMPLE) {  // Prec.hpp:151-205
+    Tmp sol1_u(h, n_u), sol1_p(h, n_p), temp_1(h, n_p), tmp(h, n_u);
+    v_copy(h, n_u, sol1_u.p(), src_u);                                                             // :168
+    v_copy(h, n_p, sol1_p.p(), src_p);                                                             // :169
+    count(st, true, gmres(h, Fm, sol1_u.p(), src_u, PF, n_u, tol * norm2(h, n_u, src_u), maxit));  // :157-173
+    spmv_B(h, sol1_u.p(), temp_1.p());                                                             // :175
+    v_add(h, n_p, temp_1.p(), -1.0, src_p);                                                        // :176
+    count(st, false, cg(h, Sm, sol1_p.p(), temp_1.p(), PS, n_p, tol * norm2(h, n_p, temp_1.p()), maxit));  // :179-182
+    v_copy(h, n_p, dst_p, sol1_p.p());                                                             // :194
+    v_scale(h, n_p, dst_p, 1. / 0.5);                                                              // :195, alpha = 0.5 (:207)
+    v_copy(h, n_u, dst_u, sol1_u.p());                                                             // :199
+    spmv_G(h, dst_p, tmp.p(), false);                                                              // :201
+    v_scale_vec(h, n_u, tmp.p(), h->diag_D_inv.p);                                                 // :202
+    v_add(h, n_u, dst_u, -1.0, tmp.p());                                                           // :203
+  } else if (type == NSX_PREC_ASIMPLE) {  // Prec.hpp:254-311 (dst is the caller's vector: its content is the initial guess)
+    Tmp tmp_u(h, n_u), tmp_p(h, n_p);
+    count(st, true, gmres(h, Fm, dst_u, src_u, PF, n_u, tol * norm2(h, n_u, src_u), maxit));  // :271-273
+    spmv_B(h, dst_u, dst_p);                                                                   // :280
+    v_sadd(h, n_p, dst_p, -1.0, 1.0, src_p);                                                   // :281
+    v_copy(h, n_p, tmp_p.p(), dst_p);                                                          // :282
+    count(st, false, gmres(h, Sm, dst_p, tmp_p.p(), PS, n_p, tol * norm2(h, n_p, tmp_p.p()), maxit));  // :287-289
+    v_scale_vec(h, n_u, dst_u, h->diag_D.p);                                                   // :294
+    v_scale(h, n_p, dst_p, 1. / 1.0);                                                          // :298, alpha = 1 (:328)
+    spmv_G(h, dst_p, tmp_u.p(), false);                                                        // :304
+    v_add(h, n_u, dst_u, -1.0, tmp_u.p());                                                     // :305
+    v_scale_vec(h, n_u, dst_u, h->diag_D_inv.p);                                               // :309
+  } else if (type == NSX_PREC_AYOSIDA) {  // Prec.hpp:474-517
+    Tmp tmp(h, n_u), tmp2(h, n_p), yu(h, n_u), yp(h, n_p), t(h, n_u);
+    v_copy(h, n_p, yp.p(), src_p);                    // :487
+    v_copy(h, n_u, tmp.p(), src_u);                   // :491
+    v_scale_vec(h, n_u, tmp.p(), h->diag_D_inv.p);    // :492
+    v_copy(h, n_u, yu.p(), tmp.p());                  // :493
+    spmv_B(h, tmp.p(), tmp2.p());                     // :496
+    v_sadd(h, n_p, yp.p(), -1.0, 1.0, tmp2.p());      // :497
+    count(st, false, cg(h, Sm, dst_p, yp.p(), PS, n_p, tol * norm2(h, n_p, yp.p()), maxit));  // :500-502
+    v_copy(h, n_p, yp.p(), dst_p);                    // :504
+    spmv_F(h, h->vF.p, yu.p(), t.p());                // :507 F->vmult(yu,yu): Epetra multiplies out of place when the arguments alias
+    v_copy(h, n_u, yu.p(), t.p());
+    spmv_G(h, yp.p(), tmp.p(), false);                // :510
+    v_sadd(h, n_u, yu.p(), -1.0, 1.0, tmp.p());       // :511
+    v_scale_vec(h, n_u, yu.p(), h->diag_D_inv.p);     // :514
+    v_copy(h, n_u, dst_u, yu.p());                    // :515
+  } else {
+    NSX_THROW(NSX_ERR_ARG, "Invalid preconditioner type");
+  }
+}
+
+void solve_time_step(nsx_handle *h, int type, double tol, double inner_rtol, int maxiter, int inner_maxiter, nsx_solve_stats *st) {
+  HIP_CHECK(hipSetDevice(h->prm.device));
+  const int n = h->n_u + h->n_p;
+  nsx_solve_stats local;
+  if (!st) st = &local;
+  memset(st, 0, sizeof(*st));
+  v_copy(h, n, h->prev_sol.p, h->sol.p);  // previous_solution = solution (NS3D.cpp:555)
+  HIP_CHECK(hipStreamSynchronize(h->stream));
+  double t0 = now_s();
+  prec_initialize(h, type);  // NS3D.cpp:568-569
+  HIP_CHECK(hipStreamSynchronize(h->stream));
+  st->t_prec = now_s() - t0;
+  t0 = now_s();
+  Op A = [h](double *d, const double *s) { spmv_saddle(h, s, d); };
+  Op P = [h, type, inner_rtol, inner_maxiter, st](double *d, const double *s) { prec_vmult(h, type, inner_rtol, inner_maxiter, d, s, st); };
+  SolveResult r = gmres(h, A, h->sol_owned.p, h->rhs.p, P, n, tol, maxiter);  // NS3D.cpp:574
+  v_copy(h, n, h->sol.p, h->sol_owned.p);  // solution = solution_owned (NS3D.cpp:638)
+  HIP_CHECK(hipStreamSynchronize(h->stream));
+  st->t_solve = now_s() - t0;
+  st->outer_iterations = r.steps;
+  st->final_residual = r.last;
+  if (r.status && st->status == 0) st->status = 1;
+}
+
+// small element-wise helper used only at initialize time
+__global__ void k_reciprocal(int n, double *__restrict__ d, const double *__restrict__ s, double num) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) d[i] = num / s[i];
+}
+void v_reciprocal(nsx_handle *h, int n, double *d, const double *s, double num) {
+  hipLaunchKernelGGL(k_reciprocal, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, n, d, s, num);
+}
+
+}  // namespace nsx
+
+#define NSX_API_BODY(h_, ...)                  \
+  if (!(h_)) return NSX_ERR_ARG;               \
+  try {                                        \
+    __VA_ARGS__;                               \
+  } catch (const nsx::Error &e) {              \
+    (h_)->err = e.msg;                         \
+    return e.code;                             \
+  } catch (const std::exception &e) {          \
+    (h_)->err = e.what();                      \
+    return NSX_ERR_ARG;                        \
+  }                                            \
+  return NSX_OK;
+
+extern "C" {
+
+int nsx_solve_time_step(nsx_handle *h, int prec_type, double tol_abs, double inner_rtol, int maxiter, int inner_maxiter,
+                        nsx_solve_stats *stats) {
+  NSX_API_BODY(h, {
+    if (!h->assembled) NSX_THROW(NSX_ERR_ARG, "assemble before solving");
+    nsx::solve_time_step(h, prec_type, tol_abs, inner_rtol, maxiter, inner_maxiter, stats);
+    if (stats && stats->status) {
+      h->err = stats->status == 1 ? "outer GMRES did not converge (SolverControl::NoConvergence)" : "an inner solve did not converge";
+      return NSX_ERR_NOCONV;
+    }
+  })
+}
+
+int nsx_prec_initialize(nsx_handle *h, int prec_type) {
+  NSX_API_BODY(h, {
+    nsx::prec_initialize(h, prec_type);
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+  })
+}
+
+int nsx_prec_vmult(nsx_handle *h, int prec_type, double inner_rtol, int inner_maxiter, double *dst, const double *src, nsx_solve_stats *stats) {
+  NSX_API_BODY(h, {
+    if (!dst || !src) NSX_THROW(NSX_ERR_ARG, "null vector");
+    HIP_CHECK(hipSetDevice(h->prm.device));
+    const int n = h->n_u + h->n_p;
+    nsx::Tmp d(h, n), s(h, n);
+    HIP_CHECK(hipMemcpyAsync(s.p(), src, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_CHECK(hipMemcpyAsync(d.p(), dst, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));  // aSIMPLE reads dst as initial guess
+    if (stats) memset(stats, 0, sizeof(*stats));
+    nsx::prec_vmult(h, prec_type, inner_rtol, inner_maxiter, d.p(), s.p(), stats);
+    HIP_CHECK(hipMemcpyAsync(dst, d.p(), (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+  })
+}
+
+int nsx_system_vmult(nsx_handle *h, double *dst, const double *src) {
+  NSX_API_BODY(h, {
+    if (!dst || !src || !h->assembled) NSX_THROW(NSX_ERR_ARG, "null vector / nothing assembled");
+    HIP_CHECK(hipSetDevice(h->prm.device));
+    const int n = h->n_u + h->n_p;
+    nsx::Tmp d(h, n), s(h, n);
+    HIP_CHECK(hipMemcpyAsync(s.p(), src, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    nsx::spmv_saddle(h, s.p(), d.p());
+    HIP_CHECK(hipMemcpyAsync(dst, d.p(), (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+  })
+}
+
+int nsx_ilu_apply(nsx_handle *h, int which, double *dst, const double *src) {
+  NSX_API_BODY(h, {
+    if (!dst || !src || which < 0 || which > 1) NSX_THROW(NSX_ERR_ARG, "bad arguments");
+    if (!h->prec_ready) NSX_THROW(NSX_ERR_ARG, "no factors: call nsx_prec_initialize first");
+    HIP_CHECK(hipSetDevice(h->prm.device));
+    const int n = which == 0 ? h->n_u : h->n_p;
+    nsx::Tmp d(h, n), s(h, n);
+    HIP_CHECK(hipMemcpyAsync(s.p(), src, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (which == 0) nsx::ilu_solve(h, h->gA, h->schedF, h->luF.p, s.p(), d.p(), h->dim, "ilu_solve_F");
+    else nsx::ilu_solve(h, h->gS, h->schedS, h->luS.p, s.p(), d.p(), 1, "ilu_solve_S");
+    HIP_CHECK(hipMemcpyAsync(dst, d.p(), (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+  })
+}
+
+}  // extern "C"

@@ -1,0 +1,435 @@
+// nsx_sparse.hip — sparse kernels of the saddle-point solve on gfx950.
+//
+//   block SpMV            system_matrix.vmult inside SolverGMRES    reference NavierStokes3D.cpp:574
+//   F / B / B_T vmult     Preconditioners.hpp:175,201,280,304,385,398,496,507,510
+//   S = B diag(v) B_T     B->mmult(negative_S, *B_T, v)              Preconditioners.hpp:144,248,358,468
+//   ILU(0) factor/solve   TrilinosWrappers::PreconditionILU          Preconditioners.hpp:147-148,215-216 (Ifpack, overlap 0)
+//
+// Layout exploited: F(0,0) = delta_cd (x) A with a scalar P2 x P2 operator A, so one 12-byte CSR entry serves the
+// dim interleaved velocity components (the reference streams dim^2 entries, 2/3 of them explicit zeros, SURVEY A-struct).
+// All kernels are HBM/L2-bandwidth bound; reductions inside a row use wavefront shuffles (64-wide waves, sub-groups of
+// 8/16/32/64 lanes per row chosen from the average row length).
+#include "nsx_internal.hpp"
+
+namespace nsx {
+
+template <int W>
+__device__ __forceinline__ double group_sum(double v) {
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, W);
+  return v;
+}
+
+// ------------------------------------------------------------------ SpMV
+// y[i][c] = sum_j A[i,j] x[j][c]  (+ sum_k G[i,k][c] xp[k]);  W lanes per row.
+template <int DIM, int W, bool WITH_G>
+__global__ __launch_bounds__(256) void k_spmv_vel(int n_rows, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                  const double *__restrict__ av, const double *__restrict__ x,
+                                                  const int32_t *__restrict__ grp, const int32_t *__restrict__ gci,
+                                                  const double *__restrict__ gv, const double *__restrict__ xp,
+                                                  double *__restrict__ y) {
+  const int row = (blockIdx.x * 256 + threadIdx.x) / W, lane = threadIdx.x % W;
+  if (row >= n_rows) return;  // whole groups exit together
+  double acc[DIM];
+#pragma unroll
+  for (int c = 0; c < DIM; ++c) acc[c] = 0.0;
+  const int e = rp[row + 1];
+  for (int p = rp[row] + lane; p < e; p += W) {
+    const double a = av[p];
+    const double *xj = x + (size_t)ci[p] * DIM;
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) acc[c] += a * xj[c];
+  }
+  if (WITH_G) {
+    const int ge = grp[row + 1];
+    for (int p = grp[row] + lane; p < ge; p += W) {
+      const double xk = xp[gci[p]];
+#pragma unroll
+      for (int c = 0; c < DIM; ++c) acc[c] += gv[(size_t)p * DIM + c] * xk;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < DIM; ++c) acc[c] = group_sum<W>(acc[c]);
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) y[(size_t)row * DIM + c] = acc[c];
+  }
+}
+
+// y_u[i][c] (+)= sum_k G[i,k][c] xp[k]
+template <int DIM, int W>
+__global__ __launch_bounds__(256) void k_spmv_G(int n_rows, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                const double *__restrict__ gv, const double *__restrict__ xp,
+                                                double *__restrict__ y, int accumulate) {
+  const int row = (blockIdx.x * 256 + threadIdx.x) / W, lane = threadIdx.x % W;
+  if (row >= n_rows) return;
+  double acc[DIM];
+#pragma unroll
+  for (int c = 0; c < DIM; ++c) acc[c] = 0.0;
+  const int e = rp[row + 1];
+  for (int p = rp[row] + lane; p < e; p += W) {
+    const double xk = xp[ci[p]];
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) acc[c] += gv[(size_t)p * DIM + c] * xk;
+  }
+#pragma unroll
+  for (int c = 0; c < DIM; ++c) acc[c] = group_sum<W>(acc[c]);
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) {
+      double *o = y + (size_t)row * DIM + c;
+      *o = accumulate ? *o + acc[c] : acc[c];
+    }
+  }
+}
+
+// y_p[i] = sum_j sum_c B[i,j][c] xu[j][c]
+template <int DIM, int W>
+__global__ __launch_bounds__(256) void k_spmv_B(int n_rows, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                const double *__restrict__ bv, const double *__restrict__ xu,
+                                                double *__restrict__ y) {
+  const int row = (blockIdx.x * 256 + threadIdx.x) / W, lane = threadIdx.x % W;
+  if (row >= n_rows) return;
+  double acc = 0.0;
+  const int e = rp[row + 1];
+  for (int p = rp[row] + lane; p < e; p += W) {
+    const double *xj = xu + (size_t)ci[p] * DIM;
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) acc += bv[(size_t)p * DIM + c] * xj[c];
+  }
+  acc = group_sum<W>(acc);
+  if (lane == 0) y[row] = acc;
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void k_spmv_csr(int n_rows, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                  const double *__restrict__ v, const double *__restrict__ x,
+                                                  double *__restrict__ y) {
+  const int row = (blockIdx.x * 256 + threadIdx.x) / W, lane = threadIdx.x % W;
+  if (row >= n_rows) return;
+  double acc = 0.0;
+  const int e = rp[row + 1];
+  for (int p = rp[row] + lane; p < e; p += W) acc += v[p] * x[ci[p]];
+  acc = group_sum<W>(acc);
+  if (lane == 0) y[row] = acc;
+}
+
+static double bytes_vel(nsx_handle *h, bool with_g) {
+  double b = 12.0 * h->gA.nnz() + (double)h->N2 * (4 + 8.0 * h->dim * 2);
+  if (with_g) b += (4.0 + 8.0 * h->dim) * h->gG.nnz() + 4.0 * h->N2 + 8.0 * h->NP;
+  return b;
+}
+
+void spmv_F(nsx_handle *h, const double *vals, const double *x, double *y) {
+  LaunchScope ls(h, "spmv_F", bytes_vel(h, false));
+  const int W = 16, grid = cdiv((int64_t)h->N2 * W, 256);
+  if (h->dim == 2)
+    hipLaunchKernelGGL((k_spmv_vel<2, W, false>), dim3(grid), dim3(256), 0, h->stream, h->N2, h->gA.rowptr.p, h->gA.colind.p, vals, x,
+                       nullptr, nullptr, nullptr, nullptr, y);
+  else
+    hipLaunchKernelGGL((k_spmv_vel<3, W, false>), dim3(grid), dim3(256), 0, h->stream, h->N2, h->gA.rowptr.p, h->gA.colind.p, vals, x,
+                       nullptr, nullptr, nullptr, nullptr, y);
+}
+
+void spmv_B(nsx_handle *h, const double *xu, double *yp) {
+  LaunchScope ls(h, "spmv_B", (4.0 + 8.0 * h->dim) * h->gB.nnz() + 12.0 * h->NP + 8.0 * h->dim * h->N2);
+  const int W = 64, grid = cdiv((int64_t)h->NP * W, 256);
+  if (h->dim == 2)
+    hipLaunchKernelGGL((k_spmv_B<2, 32>), dim3(cdiv((int64_t)h->NP * 32, 256)), dim3(256), 0, h->stream, h->NP, h->gB.rowptr.p,
+                       h->gB.colind.p, h->vB.p, xu, yp);
+  else
+    hipLaunchKernelGGL((k_spmv_B<3, W>), dim3(grid), dim3(256), 0, h->stream, h->NP, h->gB.rowptr.p, h->gB.colind.p, h->vB.p, xu, yp);
+}
+
+void spmv_G(nsx_handle *h, const double *xp, double *yu, bool accumulate) {
+  LaunchScope ls(h, "spmv_G", (4.0 + 8.0 * h->dim) * h->gG.nnz() + (double)h->N2 * (4 + 8.0 * h->dim) + 8.0 * h->NP);
+  const int W = 8, grid = cdiv((int64_t)h->N2 * W, 256);
+  if (h->dim == 2)
+    hipLaunchKernelGGL((k_spmv_G<2, W>), dim3(grid), dim3(256), 0, h->stream, h->N2, h->gG.rowptr.p, h->gG.colind.p, h->vG.p, xp, yu,
+                       (int)accumulate);
+  else
+    hipLaunchKernelGGL((k_spmv_G<3, W>), dim3(grid), dim3(256), 0, h->stream, h->N2, h->gG.rowptr.p, h->gG.colind.p, h->vG.p, xp, yu,
+                       (int)accumulate);
+}
+
+// BlockSparseMatrix::vmult: y_u = F x_u + block(0,1) x_p ; y_p = block(1,0) x_u  (block (1,1) has an empty pattern)
+void spmv_saddle(nsx_handle *h, const double *x, double *y) {
+  {
+    LaunchScope ls(h, "spmv_saddle_u", bytes_vel(h, true));
+    const int W = 16, grid = cdiv((int64_t)h->N2 * W, 256);
+    if (h->dim == 2)
+      hipLaunchKernelGGL((k_spmv_vel<2, W, true>), dim3(grid), dim3(256), 0, h->stream, h->N2, h->gA.rowptr.p, h->gA.colind.p, h->vF.p, x,
+                         h->gG.rowptr.p, h->gG.colind.p, h->vG.p, x + h->n_u, y);
+    else
+      hipLaunchKernelGGL((k_spmv_vel<3, W, true>), dim3(grid), dim3(256), 0, h->stream, h->N2, h->gA.rowptr.p, h->gA.colind.p, h->vF.p, x,
+                         h->gG.rowptr.p, h->gG.colind.p, h->vG.p, x + h->n_u, y);
+  }
+  spmv_B(h, x, y + h->n_u);
+}
+
+void spmv_S(nsx_handle *h, const double *x, double *y) {
+  LaunchScope ls(h, "spmv_S", 12.0 * h->gS.nnz() + 20.0 * h->NP);
+  const int W = 32;
+  hipLaunchKernelGGL((k_spmv_csr<W>), dim3(cdiv((int64_t)h->NP * W, 256)), dim3(256), 0, h->stream, h->NP, h->gS.rowptr.p,
+                     h->gS.colind.p, h->vSchur.p, x, y);
+}
+
+// ------------------------------------------------------------------ diagonals
+__global__ void k_extract_diag(int n_nodes, int dim, const int32_t *__restrict__ diag, const double *__restrict__ v, double *__restrict__ d) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes * dim) return;
+  d[i] = v[diag[i / dim]];
+}
+__global__ void k_abs_rowsum(int n_nodes, int dim, const int32_t *__restrict__ rp, const double *__restrict__ v, double *__restrict__ d) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes) return;
+  double s = 0.0;
+  for (int p = rp[i]; p < rp[i + 1]; ++p) s += fabs(v[p]);
+  for (int c = 0; c < dim; ++c) d[(size_t)i * dim + c] = s;
+}
+// F->diag_element(i) for every velocity dof (Prec.hpp:137,241,353,449): the scalar diagonal replicated on dim components
+void extract_diag(nsx_handle *h, const DevCsr &g, const double *vals, double *d) {
+  LaunchScope ls(h, "extract_diag", 0);
+  hipLaunchKernelGGL(k_extract_diag, dim3(cdiv(h->n_u, 256)), dim3(256), 0, h->stream, g.n_rows(), h->dim, g.diag.p, vals, d);
+}
+// sum_j |M_ij| over the row (Prec.hpp:456-465); cross-component slots of the reference's row are zero
+void abs_rowsum(nsx_handle *h, const DevCsr &g, const double *vals, double *d) {
+  LaunchScope ls(h, "abs_rowsum", 0);
+  hipLaunchKernelGGL(k_abs_rowsum, dim3(cdiv(g.n_rows(), 256)), dim3(256), 0, h->stream, g.n_rows(), h->dim, g.rowptr.p, vals, d);
+}
+
+// ------------------------------------------------------------------ S = B diag(v) B_T  (numeric phase on the static pattern)
+// block(0,1) = -block(1,0)^T with the Dirichlet rows cleared (NS3D.cpp:258,261 + apply_boundary_values), so
+//   S_ij = sum_{k in row_i(B) ^ row_j(B)} sum_c B[i,k][c] * w[k][c] * B[j,k][c],   w = -v * dirichlet_mask.
+// One wave per row i: row i (columns + dim weighted values) is staged in LDS, each lane takes one S entry (i,j),
+// walks row j of B and binary-searches its columns in the LDS copy.
+template <int DIM>
+__global__ __launch_bounds__(64) void k_schur(int n_rows, const int32_t *__restrict__ srp, const int32_t *__restrict__ sci,
+                                              const int32_t *__restrict__ brp, const int32_t *__restrict__ bci,
+                                              const double *__restrict__ bv, const double *__restrict__ w, int max_row,
+                                              double *__restrict__ sv) {
+  extern __shared__ double smem[];
+  double *rv = smem;                                  // [max_row][DIM]
+  int32_t *rc = (int32_t *)(smem + (size_t)max_row * DIM);  // [max_row]
+  const int i = blockIdx.x;
+  if (i >= n_rows) return;
+  const int b0 = brp[i], nb = brp[i + 1] - b0;
+  for (int t = threadIdx.x; t < nb; t += 64) {
+    const int k = bci[b0 + t];
+    rc[t] = k;
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) rv[t * DIM + c] = bv[(size_t)(b0 + t) * DIM + c] * w[(size_t)k * DIM + c];
+  }
+  __syncthreads();
+  for (int e = srp[i] + threadIdx.x; e < srp[i + 1]; e += 64) {
+    const int j = sci[e];
+    double acc = 0.0;
+    for (int p = brp[j]; p < brp[j + 1]; ++p) {
+      const int k = bci[p];
+      int lo = 0, hi = nb - 1, pos = -1;
+      while (lo <= hi) {
+        const int mid = (lo + hi) >> 1, cm = rc[mid];
+        if (cm < k) lo = mid + 1; else if (cm > k) hi = mid - 1; else { pos = mid; break; }
+      }
+      if (pos >= 0) {
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) acc += rv[pos * DIM + c] * bv[(size_t)p * DIM + c];
+      }
+    }
+    sv[e] = acc;
+  }
+}
+
+void schur_numeric(nsx_handle *h, const double *w) {
+  int max_row = 0;
+  const Csr &B = h->gB.host;
+  for (int i = 0; i < B.n_rows; ++i) max_row = std::max(max_row, B.rowptr[i + 1] - B.rowptr[i]);
+  const size_t shm = (size_t)max_row * (h->dim * 8 + 4) + 8;
+  if (shm > 160 * 1024) NSX_THROW(NSX_ERR_UNSUPPORTED, "row of block(1,0) too long for the Schur kernel (%d)", max_row);
+  LaunchScope ls(h, "schur_numeric", 0);
+  if (h->dim == 2)
+    hipLaunchKernelGGL((k_schur<2>), dim3(h->NP), dim3(64), shm, h->stream, h->NP, h->gS.rowptr.p, h->gS.colind.p, h->gB.rowptr.p,
+                       h->gB.colind.p, h->vB.p, w, max_row, h->vSchur.p);
+  else
+    hipLaunchKernelGGL((k_schur<3>), dim3(h->NP), dim3(64), shm, h->stream, h->NP, h->gS.rowptr.p, h->gS.colind.p, h->gB.rowptr.p,
+                       h->gB.colind.p, h->vB.p, w, max_row, h->vSchur.p);
+}
+
+// ------------------------------------------------------------------ block-Jacobi ILU(0)
+// One workgroup per rank block, rows visited level by level (levels precomputed on the static pattern, exact:
+// the arithmetic of every row is that of the sequential IKJ sweep).  Storage = Ifpack_ILU's: strict lower = L,
+// diagonal = 1/d, strict upper = U/d.  Entries whose column lies outside the block are dropped (Ifpack_LocalFilter).
+constexpr int ILU_WAVES = 4;
+constexpr int ILU_MAXROW = 1024;
+
+__global__ __launch_bounds__(ILU_WAVES * 64) void k_ilu_factor(const int32_t *__restrict__ bptr, const int32_t *__restrict__ lvl_off,
+                                                              const int32_t *__restrict__ lvl_ptr, const int32_t *__restrict__ lvl_rows,
+                                                              const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                              const int32_t *__restrict__ diag, const double *__restrict__ a,
+                                                              double *__restrict__ lu, int *__restrict__ err) {
+  __shared__ double wv[ILU_WAVES][ILU_MAXROW];
+  const int blk = blockIdx.x, wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+  const int r0 = bptr[blk], r1 = bptr[blk + 1];
+  double *w = wv[wave];
+  for (int lv = lvl_off[blk]; lv < lvl_off[blk + 1]; ++lv) {
+    const int l0 = lvl_ptr[lv], cnt = lvl_ptr[lv + 1] - l0;
+    for (int r = wave; r < cnt; r += ILU_WAVES) {
+      const int i = lvl_rows[l0 + r];
+      const int p0 = rp[i], n = rp[i + 1] - p0, dpos = diag[i] - p0;
+      if (n > ILU_MAXROW) {
+        if (lane == 0) *err = 1;
+        continue;
+      }
+      for (int t = lane; t < n; t += 64) {
+        const int j = ci[p0 + t];
+        w[t] = (j >= r0 && j < r1) ? a[p0 + t] : 0.0;
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (int t = 0; t < dpos; ++t) {  // L part, ascending columns (wave-uniform loop)
+        const int j = ci[p0 + t];
+        if (j < r0) continue;
+        const int dj = diag[j];
+        const double mult = w[t];
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) w[t] = mult * lu[dj];  // InV[jj] *= DV[j]
+        const int ue = rp[j + 1];
+        for (int q = dj + 1 + lane; q < ue; q += 64) {  // scaled U row of j
+          const int c = ci[q];
+          if (c >= r1) break;
+          int lo = t + 1, hi = n - 1;  // columns of row i are sorted; c > j
+          while (lo <= hi) {
+            const int mid = (lo + hi) >> 1, cm = ci[p0 + mid];
+            if (cm < c) lo = mid + 1; else if (cm > c) hi = mid - 1; else { w[mid] -= mult * lu[q]; break; }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      const double d = w[dpos];
+      const double dinv = 1.0 / d;
+      if (lane == 0 && !(fabs(d) > 0.0)) *err = 2;
+      for (int t = lane; t < n; t += 64) {
+        const int j = ci[p0 + t];
+        double v = w[t];
+        if (t == dpos) v = dinv;
+        else if (t > dpos) v = (j < r1) ? v * dinv : 0.0;
+        lu[p0 + t] = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();  // rows of the next level read the U rows written here (same CU: L1 is coherent for the workgroup)
+  }
+}
+
+void ilu_factor(nsx_handle *h, const DevCsr &g, const IluSchedule &s, const double *vals, double *lu, const char *name) {
+  int *err = (int *)(h->scal.p + (N_SLOTS - 1));
+  HIP_CHECK(hipMemsetAsync(err, 0, sizeof(double), h->stream));
+  {
+    LaunchScope ls(h, name, 20.0 * g.nnz() + 12.0 * g.n_rows());
+    hipLaunchKernelGGL(k_ilu_factor, dim3(s.n_blocks), dim3(ILU_WAVES * 64), 0, h->stream, s.block_ptr.p, s.blk_lvl_off.p, s.fwd_lvl_ptr.p,
+                       s.fwd_rows.p, g.rowptr.p, g.colind.p, g.diag.p, vals, lu, err);
+  }
+  int herr = 0;
+  HIP_CHECK(hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_CHECK(hipStreamSynchronize(h->stream));
+  if (herr == 1) NSX_THROW(NSX_ERR_UNSUPPORTED, "ILU: a row has more than %d entries", ILU_MAXROW);
+  if (herr == 2) NSX_THROW(NSX_ERR_NUMERIC, "ILU: zero pivot");
+}
+
+// x = U^{-1} D^{-1} L^{-1} b per block (Ifpack_ILU::ApplyInverse), NCOMP right-hand sides interleaved.
+// LW lanes cooperate on one row; the block's part of x lives in LDS when it fits (USE_LDS), else in x itself.
+template <int NCOMP, int LW, bool USE_LDS>
+__global__ __launch_bounds__(256) void k_ilu_solve(const int32_t *__restrict__ bptr, const int32_t *__restrict__ offF,
+                                                   const int32_t *__restrict__ ptrF, const int32_t *__restrict__ rowsF,
+                                                   const int32_t *__restrict__ offB, const int32_t *__restrict__ ptrB,
+                                                   const int32_t *__restrict__ rowsB, const int32_t *__restrict__ rp,
+                                                   const int32_t *__restrict__ ci, const int32_t *__restrict__ diag,
+                                                   const double *__restrict__ lu, const double *__restrict__ b, double *__restrict__ x) {
+  extern __shared__ double xs_[];
+  const int blk = blockIdx.x;
+  const int r0 = bptr[blk], r1 = bptr[blk + 1], nloc = r1 - r0;
+  double *xs = USE_LDS ? xs_ : x + (size_t)r0 * NCOMP;
+  for (int t = threadIdx.x; t < nloc * NCOMP; t += 256) xs[t] = b[(size_t)r0 * NCOMP + t];
+  __syncthreads();
+  const int grp = threadIdx.x / LW, lane = threadIdx.x % LW, ngrp = 256 / LW;
+  for (int lv = offF[blk]; lv < offF[blk + 1]; ++lv) {  // forward: y_i = b_i - sum_{j<i} L_ij y_j
+    const int l0 = ptrF[lv], cnt = ptrF[lv + 1] - l0;
+    for (int r = grp; r < cnt; r += ngrp) {
+      const int i = rowsF[l0 + r];
+      double acc[NCOMP];
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) acc[c] = 0.0;
+      const int e = diag[i];
+      for (int p = rp[i] + lane; p < e; p += LW) {
+        const int j = ci[p];
+        if (j >= r0) {
+          const double l = lu[p];
+#pragma unroll
+          for (int c = 0; c < NCOMP; ++c) acc[c] += l * xs[(j - r0) * NCOMP + c];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) acc[c] = group_sum<LW>(acc[c]);
+      if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c) xs[(i - r0) * NCOMP + c] -= acc[c];
+      }
+    }
+    __syncthreads();
+  }
+  for (int t = threadIdx.x; t < nloc; t += 256) {  // y *= D^{-1}
+    const double dinv = lu[diag[r0 + t]];
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) xs[t * NCOMP + c] *= dinv;
+  }
+  __syncthreads();
+  for (int lv = offB[blk]; lv < offB[blk + 1]; ++lv) {  // backward: x_i = y_i - sum_{j>i} U_ij x_j
+    const int l0 = ptrB[lv], cnt = ptrB[lv + 1] - l0;
+    for (int r = grp; r < cnt; r += ngrp) {
+      const int i = rowsB[l0 + r];
+      double acc[NCOMP];
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) acc[c] = 0.0;
+      const int e = rp[i + 1];
+      for (int p = diag[i] + 1 + lane; p < e; p += LW) {
+        const int j = ci[p];
+        if (j < r1) {
+          const double u = lu[p];
+#pragma unroll
+          for (int c = 0; c < NCOMP; ++c) acc[c] += u * xs[(j - r0) * NCOMP + c];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) acc[c] = group_sum<LW>(acc[c]);
+      if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c) xs[(i - r0) * NCOMP + c] -= acc[c];
+      }
+    }
+    __syncthreads();
+  }
+  if (USE_LDS)
+    for (int t = threadIdx.x; t < nloc * NCOMP; t += 256) x[(size_t)r0 * NCOMP + t] = xs[t];
+}
+
+template <int NCOMP>
+static void launch_ilu_solve(nsx_handle *h, const DevCsr &g, const IluSchedule &s, const double *lu, const double *b, double *x) {
+  const size_t shm = (size_t)s.max_rows * NCOMP * sizeof(double);
+  constexpr int LW = 8;
+#define NSX_ILU_ARGS s.block_ptr.p, s.blk_lvl_off.p, s.fwd_lvl_ptr.p, s.fwd_rows.p, s.blk_lvl_off_b.p, s.bwd_lvl_ptr.p, s.bwd_rows.p, \
+                     g.rowptr.p, g.colind.p, g.diag.p, lu, b, x
+  if (shm <= 64 * 1024)
+    hipLaunchKernelGGL((k_ilu_solve<NCOMP, LW, true>), dim3(s.n_blocks), dim3(256), shm, h->stream, NSX_ILU_ARGS);
+  else
+    hipLaunchKernelGGL((k_ilu_solve<NCOMP, LW, false>), dim3(s.n_blocks), dim3(256), 0, h->stream, NSX_ILU_ARGS);
+#undef NSX_ILU_ARGS
+}
+
+void ilu_solve(nsx_handle *h, const DevCsr &g, const IluSchedule &s, const double *lu, const double *b, double *x, int ncomp,
+               const char *name) {
+  LaunchScope ls(h, name, 12.0 * g.nnz() + (double)g.n_rows() * (4 + 16.0 * ncomp));
+  if (ncomp == 1) launch_ilu_solve<1>(h, g, s, lu, b, x);
+  else if (ncomp == 2) launch_ilu_solve<2>(h, g, s, lu, b, x);
+  else launch_ilu_solve<3>(h, g, s, lu, b, x);
+}
+
+}  // namespace nsx

@@ -1,0 +1,266 @@
+"""ctypes binding of the device library (include/nsx.h -> csrc/libnsx.so).
+
+Plumbing for tests and bench.py only.  There is no CPU fallback: without a HIP device `Nsx(...)` raises,
+and without the built library the import of the symbols raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import DEV_SO, load
+
+_i32p = C.POINTER(C.c_int32)
+_f64p = C.POINTER(C.c_double)
+
+TEMAM, DOUBLE_CONVECTION = 1, 2
+YOSIDA, SIMPLE, AYOSIDA, ASIMPLE = 0, 1, 2, 3
+
+# every symbol include/nsx.h declares (tests check that the library exports all of them)
+API = [
+    "nsx_create", "nsx_destroy", "nsx_last_error", "nsx_version", "nsx_set_tables", "nsx_set_mesh", "nsx_set_ranks",
+    "nsx_set_schur_blocks", "nsx_set_solution", "nsx_get_solution", "nsx_get_solution_ghosted", "nsx_get_rhs",
+    "nsx_set_rhs", "nsx_assemble", "nsx_assemble_time_step", "nsx_add_rhs", "nsx_apply_boundary_values",
+    "nsx_solve_time_step", "nsx_prec_initialize", "nsx_prec_vmult", "nsx_system_vmult", "nsx_ilu_apply",
+    "nsx_export_block", "nsx_schur_nnz", "nsx_schur_get", "nsx_scalar_graph_nnz", "nsx_scalar_graph", "nsx_ilu_get",
+    "nsx_profile_enable", "nsx_profile_reset", "nsx_profile_count", "nsx_profile_get", "nsx_comm_unique_id",
+    "nsx_comm_init", "nsx_set_mesh_distributed",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [("dim", C.c_int), ("device", C.c_int), ("nu", C.c_double), ("deltat", C.c_double)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("outer_iterations", C.c_int), ("inner_F_iterations", C.c_int), ("inner_S_iterations", C.c_int),
+                ("n_F_solves", C.c_int), ("n_S_solves", C.c_int), ("final_residual", C.c_double),
+                ("t_prec", C.c_double), ("t_solve", C.c_double), ("status", C.c_int)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class NsxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("nsx error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib():
+    L = load(DEV_SO)
+    if getattr(L, "_nsx_ready", False):
+        return L
+    vp = C.c_void_p
+    L.nsx_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
+    L.nsx_destroy.argtypes = [vp]
+    L.nsx_last_error.restype = C.c_char_p
+    L.nsx_last_error.argtypes = [vp]
+    L.nsx_version.restype = C.c_char_p
+    L.nsx_set_tables.argtypes = [vp, C.c_int, C.c_int, C.c_int, _f64p, _f64p, _f64p, _f64p]
+    L.nsx_set_mesh.argtypes = [vp, C.c_int, C.c_int, _i32p, _f64p, C.c_int, C.c_int]
+    L.nsx_set_ranks.argtypes = [vp, C.c_int, _i32p, _i32p]
+    L.nsx_set_schur_blocks.argtypes = [vp, C.c_int, _i32p]
+    for f in ("nsx_set_solution", "nsx_get_solution", "nsx_get_solution_ghosted", "nsx_get_rhs", "nsx_set_rhs"):
+        getattr(L, f).argtypes = [vp, _f64p]
+    L.nsx_assemble.argtypes = [vp, C.c_int]
+    L.nsx_assemble_time_step.argtypes = [vp, C.c_int]
+    L.nsx_add_rhs.argtypes = [vp, C.c_int, _i32p, _f64p]
+    L.nsx_apply_boundary_values.argtypes = [vp, C.c_int, _i32p, _f64p]
+    L.nsx_solve_time_step.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, C.POINTER(Stats)]
+    L.nsx_prec_initialize.argtypes = [vp, C.c_int]
+    L.nsx_prec_vmult.argtypes = [vp, C.c_int, C.c_double, C.c_int, _f64p, _f64p, C.POINTER(Stats)]
+    L.nsx_system_vmult.argtypes = [vp, _f64p, _f64p]
+    L.nsx_ilu_apply.argtypes = [vp, C.c_int, _f64p, _f64p]
+    L.nsx_export_block.argtypes = [vp, C.c_int, C.c_int, C.c_int, _i32p, _i32p, _f64p]
+    L.nsx_schur_nnz.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.nsx_schur_get.argtypes = [vp, _i32p, _i32p, _f64p]
+    L.nsx_scalar_graph_nnz.argtypes = [vp, C.c_int, C.POINTER(C.c_int64)]
+    L.nsx_scalar_graph.argtypes = [vp, C.c_int, _i32p, _i32p]
+    L.nsx_ilu_get.argtypes = [vp, C.c_int, _f64p]
+    L.nsx_profile_enable.argtypes = [vp, C.c_int]
+    L.nsx_profile_reset.argtypes = [vp]
+    L.nsx_profile_count.argtypes = [vp]
+    L.nsx_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), _f64p, _f64p]
+    L.nsx_comm_unique_id.argtypes = [C.POINTER(C.c_uint8)]
+    L.nsx_comm_init.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_uint8)]
+    L._nsx_ready = True
+    return L
+
+
+def _i(a):
+    return a.ctypes.data_as(_i32p)
+
+
+def _d(a):
+    return a.ctypes.data_as(_f64p)
+
+
+def _ci(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _cd(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Nsx:
+    """One device-side `NavierStokes` problem (a handle of libnsx)."""
+
+    def __init__(self, dofs, tables, nu, deltat, device=0):
+        L = lib()
+        self.L = L
+        self._h = C.c_void_p()
+        prm = Params(dofs.dim, device, float(nu), float(deltat))
+        rc = L.nsx_create(C.byref(prm), C.byref(self._h))
+        if rc:
+            raise NsxError(rc, (L.nsx_last_error(None) or b"").decode())
+        self.dim, self.n_u, self.n_p = dofs.dim, dofs.n_u, dofs.n_p
+        self.n = self.n_u + self.n_p
+        self.dofs = dofs
+        N2, dN2, N1, w = _cd(tables.N2), _cd(tables.dN2), _cd(tables.N1), _cd(tables.weights)
+        self._ck(L.nsx_set_tables(self._h, tables.n_q, tables.n_p2, tables.n_p1, _d(N2), _d(dN2), _d(N1), _d(w)))
+        cd, cc = _ci(dofs.cell_dofs), _cd(dofs.cell_coords)
+        self._ck(L.nsx_set_mesh(self._h, dofs.n_cells, dofs.dofs_per_cell, _i(cd), _d(cc), dofs.n_u, dofs.n_p))
+        if dofs.n_subdomains > 1:
+            self.set_ranks(dofs.owned_u_ptr, dofs.owned_p_ptr)
+
+    def _ck(self, rc):
+        if rc:
+            raise NsxError(rc, (self.L.nsx_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if self._h:
+            self.L.nsx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- setup ---------------------------------------------------------------------------------
+    def set_ranks(self, u_ptr, p_ptr):
+        u_ptr, p_ptr = _ci(u_ptr), _ci(p_ptr)
+        self._ck(self.L.nsx_set_ranks(self._h, len(u_ptr) - 1, _i(u_ptr), _i(p_ptr)))
+
+    def set_schur_blocks(self, p_ptr):
+        p_ptr = _ci(p_ptr)
+        self._ck(self.L.nsx_set_schur_blocks(self._h, len(p_ptr) - 1, _i(p_ptr)))
+
+    # -- state ---------------------------------------------------------------------------------
+    def set_solution(self, v):
+        v = _cd(v)
+        assert v.shape == (self.n,)
+        self._ck(self.L.nsx_set_solution(self._h, _d(v)))
+
+    def _get(self, fn):
+        v = np.empty(self.n)
+        self._ck(fn(self._h, _d(v)))
+        return v
+
+    @property
+    def solution_owned(self):
+        return self._get(self.L.nsx_get_solution)
+
+    @property
+    def solution(self):
+        return self._get(self.L.nsx_get_solution_ghosted)
+
+    @property
+    def rhs(self):
+        return self._get(self.L.nsx_get_rhs)
+
+    def set_rhs(self, v):
+        v = _cd(v)
+        self._ck(self.L.nsx_set_rhs(self._h, _d(v)))
+
+    # -- hot path ------------------------------------------------------------------------------
+    def assemble(self, flags=0):
+        self._ck(self.L.nsx_assemble(self._h, flags))
+
+    def assemble_time_step(self, flags=0):
+        self._ck(self.L.nsx_assemble_time_step(self._h, flags))
+
+    def add_rhs(self, dofs, vals):
+        dofs, vals = _ci(dofs), _cd(vals)
+        self._ck(self.L.nsx_add_rhs(self._h, len(dofs), _i(dofs), _d(vals)))
+
+    def apply_boundary_values(self, dofs, vals):
+        dofs, vals = _ci(dofs), _cd(vals)
+        self._ck(self.L.nsx_apply_boundary_values(self._h, len(dofs), _i(dofs), _d(vals)))
+
+    def solve_time_step(self, prec=YOSIDA, tol_abs=1e-4, inner_rtol=1e-2, maxiter=100000, inner_maxiter=100000,
+                        check=True):
+        st = Stats()
+        rc = self.L.nsx_solve_time_step(self._h, prec, tol_abs, inner_rtol, maxiter, inner_maxiter, C.byref(st))
+        if rc and (check or rc != -4):
+            self._ck(rc)
+        return st.as_dict()
+
+    def prec_initialize(self, prec):
+        self._ck(self.L.nsx_prec_initialize(self._h, prec))
+
+    def prec_vmult(self, prec, src, inner_rtol=1e-2, inner_maxiter=100000, dst0=None):
+        src = _cd(src)
+        dst = np.zeros_like(src) if dst0 is None else _cd(dst0).copy()
+        st = Stats()
+        self._ck(self.L.nsx_prec_vmult(self._h, prec, inner_rtol, inner_maxiter, _d(dst), _d(src), C.byref(st)))
+        return dst, st.as_dict()
+
+    def system_vmult(self, src):
+        src = _cd(src)
+        dst = np.empty_like(src)
+        self._ck(self.L.nsx_system_vmult(self._h, _d(dst), _d(src)))
+        return dst
+
+    def ilu_apply(self, which, src):
+        src = _cd(src)
+        dst = np.empty_like(src)
+        self._ck(self.L.nsx_ilu_apply(self._h, which, _d(dst), _d(src)))
+        return dst
+
+    # -- export --------------------------------------------------------------------------------
+    def export_block(self, which, block, graph=None):
+        """values of matrix `which` in the reference's padded block-CSR graph (default: the front-end's)."""
+        rowptr, colind = graph if graph is not None else self.dofs.reference_sparsity(3 if which == 4 else block)
+        rowptr, colind = _ci(rowptr), _ci(colind)
+        vals = np.empty(len(colind))
+        self._ck(self.L.nsx_export_block(self._h, which, block, len(rowptr) - 1, _i(rowptr), _i(colind), _d(vals)))
+        return vals
+
+    def scalar_graph(self, which):
+        nnz = C.c_int64()
+        self._ck(self.L.nsx_scalar_graph_nnz(self._h, which, C.byref(nnz)))
+        n = (self.n_u // self.dim) if which == 0 else self.n_p
+        rp, ci = np.empty(n + 1, np.int32), np.empty(nnz.value, np.int32)
+        self._ck(self.L.nsx_scalar_graph(self._h, which, _i(rp), _i(ci)))
+        return rp, ci
+
+    def schur(self):
+        import scipy.sparse as sp
+        rp, ci = self.scalar_graph(1)
+        v = np.empty(len(ci))
+        self._ck(self.L.nsx_schur_get(self._h, _i(rp), _i(ci), _d(v)))
+        return sp.csr_matrix((v, ci, rp), shape=(self.n_p, self.n_p))
+
+    def ilu(self, which):
+        rp, ci = self.scalar_graph(which)
+        v = np.empty(len(ci))
+        self._ck(self.L.nsx_ilu_get(self._h, which, _d(v)))
+        return rp, ci, v
+
+    # -- measurement ---------------------------------------------------------------------------
+    def profile(self, on=True):
+        self._ck(self.L.nsx_profile_enable(self._h, int(on)))
+
+    def profile_reset(self):
+        self._ck(self.L.nsx_profile_reset(self._h))
+
+    def profile_table(self):
+        out = {}
+        for i in range(self.L.nsx_profile_count(self._h)):
+            name, n, ms, b = C.c_char_p(), C.c_int64(), C.c_double(), C.c_double()
+            self.L.nsx_profile_get(self._h, i, C.byref(name), C.byref(n), C.byref(ms), C.byref(b))
+            out[name.value.decode()] = {"launches": n.value, "total_ms": ms.value, "bytes_per_launch": b.value}
+        return out

@@ -1,0 +1,55 @@
+"""Development probe run on the GPU box: a failing scenario + first timings of the ~1M-DoF 3D cylinder."""
+import sys, time, json, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+from navierstokes_project_nm4pde_amd.frontend import Mesh, DoFs, Tables
+from navierstokes_project_nm4pde_amd import nsx
+from navierstokes_project_nm4pde_amd.problem import InletVelocity, cylinder_boundary_values
+
+what = sys.argv[1]
+if what == "cube":
+    from conftest import Problem
+    from test_gpu_parity import _bc
+    p = Problem("cube", 3, 3)
+    dev = p.device(); u = p.smooth_velocity(); dev.set_solution(u)
+    dev.assemble(3); bd, bv = _bc(p, p.deltat); dev.apply_boundary_values(bd, bv)
+    t = p.deltat
+    for prec in (0, 3):
+        for step in range(2):
+            t += p.deltat
+            dev.assemble_time_step(1); bd, bv = _bc(p, t); dev.apply_boundary_values(bd, bv)
+            print(dev.solve_time_step(prec, tol_abs=1e-11, inner_rtol=1e-10, check=False))
+    dev.assemble_time_step(1); bd, bv = _bc(p, 4 * p.deltat); dev.apply_boundary_values(bd, bv)
+    print(dev.solve_time_step(0, maxiter=300, check=False))
+    print("sol finite", np.isfinite(dev.solution_owned).all())
+else:
+    lvl, nsub, ssub = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    m = Mesh.cylinder(3, lvl).partition(1, nsub)
+    d, tb = DoFs(m), Tables(3)
+    print("dofs", d.n_dofs, "cells", d.n_cells, flush=True)
+    t0 = time.time(); dev = nsx.Nsx(d, tb, 1e-3, 2e-4); print("setup %.1fs" % (time.time() - t0), flush=True)
+    if ssub > 0:
+        step = nsub // ssub
+        dev.set_schur_blocks(d.owned_p_ptr[::step])
+    inlet = InletVelocity(3)
+    dev.set_solution(np.zeros(d.n_dofs))
+    tm = 0.0
+    for step in range(1, 7):
+        tm += 2e-4
+        if step == 4:
+            dev.profile(True)
+        t0 = time.time()
+        if step == 1: dev.assemble(nsx.TEMAM)
+        else: dev.assemble_time_step(0)
+        bd, bv = cylinder_boundary_values(d, inlet, tm)
+        dev.apply_boundary_values(bd, bv)
+        ta = time.time() - t0
+        st = dev.solve_time_step(nsx.YOSIDA, check=False)
+        print(step, "asm+bc %.4fs" % ta, st, flush=True)
+    tab = dev.profile_table()
+    tot = sum(v["total_ms"] for v in tab.values())
+    for k, v in sorted(tab.items(), key=lambda kv: -kv[1]["total_ms"]):
+        avg = v["total_ms"] / max(1, v["launches"])
+        bw = v["bytes_per_launch"] / (avg * 1e-3) / 1e9 if avg > 0 else 0
+        print("%-18s n=%6d total %9.2f ms (%4.1f%%) avg %8.1f us  alg %8.1f GB/s" % (k, v["launches"], v["total_ms"], 100 * v["total_ms"] / tot, avg * 1e3, bw))
