@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py — time-steps/sec of the per-time-step hot path on the 3D flow-past-cylinder problem.
+
+One "step" = NavierStokes::assemble_time_step + apply_boundary_values + solve_time_step
+(reference Navier-Stokes/src/NavierStokes3D.cpp:721-724) on the ~1M-DoF P2/P1 tetrahedral mesh
+(BASELINE.json configs[1]), Yosida preconditioner, reference tolerances (1e-4 abs outer, 1e-2 rel inner),
+dt = 2e-4, nu = 1e-3, u_m = 9 (reference defaults).  Inputs are resident in HBM when the timed
+region starts; VTU output and forces are excluded.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--level L] [--ranks R] [--schur-blocks S]
+
+For N > 1 the driver launches one process per GPU with torch.distributed.run (RCCL).  This round every rank
+advances its own replica of the workload ("replicas only": the owned+ghost distributed mesh path is not
+finished), so per-GPU work is fixed and `scaling` is "weak".
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def build_problem(level, ranks):
+    from navierstokes_project_nm4pde_amd.frontend import DoFs, Mesh, Tables
+    mesh = Mesh.cylinder(3, level).partition(1, ranks)
+    return mesh, DoFs(mesh), Tables(3)
+
+
+def gpu_run(dofs, tables, steps, warmup, schur_blocks, device, profile_steps=2, barrier=None):
+    import numpy as np
+    from navierstokes_project_nm4pde_amd import nsx
+    from navierstokes_project_nm4pde_amd.problem import InletVelocity, cylinder_boundary_values
+    nu, dt = 1e-3, 2e-4
+    dev = nsx.Nsx(dofs, tables, nu, dt, device=device)
+    if schur_blocks and schur_blocks < dofs.n_subdomains:
+        stride = max(1, dofs.n_subdomains // schur_blocks)
+        ptr = list(dofs.owned_p_ptr[::stride])
+        if ptr[-1] != dofs.n_p:
+            ptr.append(dofs.n_p)
+        dev.set_schur_blocks(np.array(ptr, dtype=np.int32))
+    inlet = InletVelocity(3)  # test case 2, u_m = 9 (reference NavierStokes3D.hpp:37,80)
+    dev.set_solution(np.zeros(dofs.n_dofs))  # u_0 = 0 (reference NavierStokes3D.hpp:200)
+    t = 0.0
+    stats = []
+
+    def one_step(first):
+        nonlocal t
+        t += dt
+        if first:
+            dev.assemble(nsx.TEMAM)
+        else:
+            dev.assemble_time_step(0)
+        bd, bv = cylinder_boundary_values(dofs, inlet, t)
+        dev.apply_boundary_values(bd, bv)
+        return dev.solve_time_step(nsx.YOSIDA)  # raises on non-convergence
+
+    one_step(True)  # the first step is the full assembly (reported separately by the reference)
+    for _ in range(warmup):
+        one_step(False)
+    if barrier:
+        barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        stats.append(one_step(False))
+    if barrier:
+        barrier()
+    elapsed = time.perf_counter() - t0
+    # per-kernel HIP-event pass (separate from the throughput pass: event pairs perturb the launch stream)
+    table = {}
+    if profile_steps:
+        dev.profile(True)
+        for _ in range(profile_steps):
+            one_step(False)
+        table = dev.profile_table()
+        dev.profile(False)
+    dev.close()
+    return elapsed, stats, table
+
+
+def cpu_baseline(level=2, ranks=16):
+    """Oracle (CPU restatement of the reference algorithm, 1 core) on a bounded sample of the same workload."""
+    import numpy as np
+    import oracle
+    from navierstokes_project_nm4pde_amd.problem import InletVelocity, cylinder_boundary_values
+    mesh, dofs, tables = build_problem(level, ranks)
+    nu, dt = 1e-3, 2e-4
+    o = oracle.Oracle(dofs, tables, nu, dt)
+    inlet = InletVelocity(3)
+    o.assemble(oracle.TEMAM)
+    bd, bv = cylinder_boundary_values(dofs, inlet, dt)
+    o.apply_boundary_values(bd, bv)
+    o.solve_time_step(oracle.YOSIDA)
+    t0 = time.perf_counter()
+    o.assemble_time_step(0)
+    bd, bv = cylinder_boundary_values(dofs, inlet, 2 * dt)
+    o.apply_boundary_values(bd, bv)
+    st = o.solve_time_step(oracle.YOSIDA)
+    el = time.perf_counter() - t0
+    return dofs, tables, {"value": 1.0 / el, "unit": "time-steps/s", "cores": 1, "kind": "port",
+                          "sample": "1 time step (assemble_time_step + Dirichlet + Yosida solve_time_step) of the same 3D cylinder "
+                                    "problem on a %d-DoF mesh (level %d, %d ranks), oracle/nsx_oracle.c, gcc -O3, %d outer its"
+                                    % (dofs.n_dofs, level, ranks, st["outer_iterations"]),
+                          "sample_dofs": dofs.n_dofs, "sample_seconds": el}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--level", type=int, default=7, help="mesh level (7 ~ 1.09M DoF)")
+    ap.add_argument("--ranks", type=int, default=4096, help="virtual MPI ranks = ILU(0) blocks of F")
+    ap.add_argument("--schur-blocks", type=int, default=512, help="ILU(0) blocks of the Schur matrix")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    barrier = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl")
+        def barrier():
+            dist.barrier()
+            torch.cuda.synchronize()
+    else:
+        def barrier():
+            torch.cuda.synchronize()
+
+    mesh, dofs, tables = build_problem(args.level, args.ranks)
+    elapsed, stats, table = gpu_run(dofs, tables, args.steps, args.warmup, args.schur_blocks, local_rank,
+                                    profile_steps=2 if rank == 0 else 0, barrier=barrier)
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    steps_per_s = world * args.steps / elapsed
+    outer = sum(s["outer_iterations"] for s in stats)
+    t_solve = sum(s["t_solve"] for s in stats)
+    # roofline of the dominant kernel (by summed HIP-event time over the profiled steps)
+    kernels = {}
+    for k, v in table.items():
+        if v["launches"] == 0:
+            continue
+        avg_s = v["total_ms"] * 1e-3 / v["launches"]
+        kernels[k] = {"launches_per_step": v["launches"] / 2.0, "avg_us": avg_s * 1e6,
+                      "alg_GBps": (v["bytes_per_launch"] / avg_s / 1e9) if avg_s > 0 and v["bytes_per_launch"] > 0 else None,
+                      "share": v["total_ms"]}
+    tot = sum(v["share"] for v in kernels.values()) or 1.0
+    for v in kernels.values():
+        v["share"] = v["share"] / tot
+    dom = max((k for k in kernels if kernels[k]["alg_GBps"]), key=lambda k: kernels[k]["share"]) if kernels else None
+    roof = None
+    if dom:
+        a = kernels[dom]["alg_GBps"]
+        roof = {"kernel": dom, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
+                "traffic": None, "avg_us": kernels[dom]["avg_us"], "share_of_kernel_time": kernels[dom]["share"]}
+        if "spmv_F" in kernels and kernels["spmv_F"]["alg_GBps"]:
+            roof["spmv_F_GBps"] = kernels["spmv_F"]["alg_GBps"]
+            roof["spmv_F_frac"] = kernels["spmv_F"]["alg_GBps"] / HBM_PEAK_GBS
+    out = {
+        "metric": "time-steps/sec (assemble_time_step + solve_time_step), 3D flow past a cylinder, P2/P1, Yosida",
+        "value": steps_per_s, "unit": "time-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic (block-structured tetrahedral cylinder mesh, u0 = 0, reference inlet profile)",
+        "config": {"workload": "3D flow-past-cylinder, P2/P1 (reference FE_SimplexP), %d DoF, %d cells, dt=2e-4, nu=1e-3, u_m=9, "
+                               "GMRES(1e-4 abs)+Yosida(inner 1e-2), ILU(0) per rank with %d ranks (Schur: %d blocks)"
+                               % (dofs.n_dofs, dofs.n_cells, args.ranks, args.schur_blocks),
+                   "n_dofs": dofs.n_dofs, "n_cells": dofs.n_cells, "mode": "replicas" if world > 1 else "single"},
+        "gmres_outer_iters_per_step": outer / max(1, len(stats)),
+        "gmres_outer_iters_per_sec": outer / t_solve if t_solve > 0 else None,
+        "inner_F_iters_per_step": sum(s["inner_F_iterations"] for s in stats) / max(1, len(stats)),
+        "inner_S_iters_per_step": sum(s["inner_S_iterations"] for s in stats) / max(1, len(stats)),
+        "roofline": roof,
+        "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kernels.items()},
+    }
+    if world == 1 and not args.no_cpu:
+        import multiprocessing
+        sd, st, cb = cpu_baseline()
+        # the same sample on the GPU, for a like-for-like ratio
+        e2, _, _ = gpu_run(sd, st, 3, 1, 0, local_rank, profile_steps=0)
+        cb["gpu_same_sample_steps_per_s"] = 3 / e2
+        cb["host_cores_available"] = multiprocessing.cpu_count()
+        cb["estimate_full_workload_steps_per_s"] = cb["value"] * cb["sample_dofs"] / dofs.n_dofs
+        out["cpu_baseline"] = cb
+    print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -20,7 +20,7 @@ __device__ __forceinline__ double sval(const double *__restrict__ scal, SRef r) 
   return v;
 }
 
-constexpr int RED_BLOCKS = 256;
+constexpr int RED_BLOCKS = 1024;
 constexpr int RED_STRIDE = 1024;  // partial slots per reduction
 
 __device__ __forceinline__ double block_sum_256(double v, double *sh) {

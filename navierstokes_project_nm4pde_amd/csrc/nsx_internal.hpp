@@ -102,6 +102,15 @@ struct IluSchedule {
   DevBuf<int32_t> blk_lvl_off;           // [n_blocks+1] offsets into fwd_lvl_ptr (levels per block), same for bwd
   DevBuf<int32_t> blk_lvl_off_b;
   int max_levels = 0;
+  // packed wave-per-block solve stream: slabs of 64 slots {value, meta}; meta = col | last_of_step<<15 | (dst_row+1)<<16
+  int lanes_per_row = 8;
+  int64_t n_slabs = 0;
+  bool packed_ok = false;
+  DevBuf<int32_t> pk_slab_ptr;  // [2*n_blocks+1]: forward slabs, then backward slabs, per block
+  DevBuf<int32_t> pk_meta;      // [n_slabs*64]
+  DevBuf<int32_t> pk_slot_of;   // [nnz]: slot of every in-block off-diagonal CSR entry, -1 otherwise
+  DevBuf<double> pk_val;        // [n_slabs*64] factor values in stream order (padding slots stay 0)
+  DevBuf<double> pk_dinv;       // [n_rows] inverse pivots
 };
 
 struct ProfEntry {
@@ -187,7 +196,7 @@ struct LaunchScope {
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // ---- kernels / steps implemented across the .hip files
-void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> &block_ptr, IluSchedule &s);
+void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> &block_ptr, IluSchedule &s, int lanes_per_row);
 void build_schur_graph(nsx_handle *h);
 
 // assembly (nsx_assemble.hip)
@@ -201,7 +210,7 @@ void spmv_G(nsx_handle *h, const double *xp, double *yu, bool accumulate);      
 void spmv_B(nsx_handle *h, const double *xu, double *yp);                                   // y_p = block(1,0) x_u
 void spmv_S(nsx_handle *h, const double *x, double *y);                                     // y = negative_S x
 void schur_numeric(nsx_handle *h, const double *w);                                         // S = B diag(w) G
-void ilu_factor(nsx_handle *h, const DevCsr &g, const IluSchedule &s, const double *vals, double *lu, const char *name);
+void ilu_factor(nsx_handle *h, const DevCsr &g, IluSchedule &s, const double *vals, double *lu, const char *name);
 void ilu_solve(nsx_handle *h, const DevCsr &g, const IluSchedule &s, const double *lu, const double *b, double *x, int ncomp,
                const char *name);
 void extract_diag(nsx_handle *h, const DevCsr &g, const double *vals, double *d);           // scalar diag

@@ -59,7 +59,7 @@ static void build_gather(nsx_handle *h, const Csr &g, int n_cells, int per_r, co
   gm.src.upload(src, h->stream);
 }
 
-void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> &bptr, IluSchedule &s) {
+void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> &bptr, IluSchedule &s, int lanes_per_row) {
   const int nb = (int)bptr.size() - 1;
   s.n_blocks = nb;
   s.block_ptr_h = bptr;
@@ -118,6 +118,91 @@ void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> 
   s.bwd_rows.upload(b_rows, h->stream);
   s.blk_lvl_off.upload(off_f, h->stream);
   s.blk_lvl_off_b.upload(off_b, h->stream);
+
+  // ---- packed stream for the wave-per-block solve (nsx_sparse.hip: k_ilu_solve_packed)
+  // A step = up to G = 64/LW independent rows of one level, LW lanes per row; it occupies K slabs of 64 slots,
+  // slot (k, lane) = entry lane%LW + k*LW of row lane/LW.  Rows without in-block entries need no work.
+  const int LW = lanes_per_row, G = 64 / LW;
+  s.lanes_per_row = LW;
+  s.packed_ok = s.max_rows <= 32767;
+  if (!s.packed_ok) return;
+  std::vector<int32_t> slab_ptr(2 * (size_t)nb + 1, 0), meta, slot_of(g.nnz(), -1);
+  auto pack_dir = [&](int b, bool fwd) {
+    const int r0 = bptr[b], r1 = bptr[b + 1];
+    const auto &ptr = fwd ? f_ptr : b_ptr;
+    const auto &rows = fwd ? f_rows : b_rows;
+    const auto &off = fwd ? off_f : off_b;
+    for (int lv = off[b]; lv < off[b + 1]; ++lv) {
+      std::vector<int32_t> work;  // rows of this level that have in-block entries
+      for (int k = ptr[lv]; k < ptr[lv + 1]; ++k) {
+        const int i = rows[k];
+        bool any = false;
+        for (int q = g.rowptr[i]; q < g.rowptr[i + 1] && !any; ++q) {
+          const int j = g.colind[q];
+          any = fwd ? (j >= r0 && j < i) : (j > i && j < r1);
+        }
+        if (any) work.push_back(i);
+      }
+      for (size_t w0 = 0; w0 < work.size(); w0 += G) {
+        const int ng = (int)std::min<size_t>(G, work.size() - w0);
+        std::vector<std::vector<int32_t>> ent(ng);
+        int K = 1;
+        for (int gi = 0; gi < ng; ++gi) {
+          const int i = work[w0 + gi];
+          for (int q = g.rowptr[i]; q < g.rowptr[i + 1]; ++q) {
+            const int j = g.colind[q];
+            if (fwd ? (j >= r0 && j < i) : (j > i && j < r1)) ent[gi].push_back(q);
+          }
+          K = std::max(K, ((int)ent[gi].size() + LW - 1) / LW);
+        }
+        for (int k = 0; k < K; ++k) {
+          const size_t base = meta.size();
+          meta.resize(base + 64, 0);
+          for (int lane = 0; lane < 64; ++lane) {
+            const int gi = lane / LW, l = lane % LW;
+            int32_t m = (k == K - 1) ? 0x8000 : 0;
+            if (gi < ng) {
+              const size_t e = (size_t)l + (size_t)k * LW;
+              if (e < ent[gi].size()) {
+                const int q = ent[gi][e];
+                m |= (g.colind[q] - r0);
+                slot_of[q] = (int32_t)(base + lane);
+              }
+              if (k == K - 1 && l == 0) m |= (work[w0 + gi] - r0 + 1) << 16;
+            }
+            meta[base + lane] = m;
+          }
+        }
+      }
+    }
+  };
+  for (int b = 0; b < nb; ++b) {
+    pack_dir(b, true);
+    slab_ptr[2 * (size_t)b + 1] = (int32_t)(meta.size() / 64);
+    pack_dir(b, false);
+    slab_ptr[2 * (size_t)b + 2] = (int32_t)(meta.size() / 64);
+  }
+  s.n_slabs = (int64_t)meta.size() / 64;
+  if (getenv("NSX_DEBUG")) {
+    int64_t max_slabs = 0, steps = 0, max_steps = 0, used = 0;
+    for (int b = 0; b < nb; ++b) {
+      max_slabs = std::max<int64_t>(max_slabs, slab_ptr[2 * b + 2] - slab_ptr[2 * b]);
+      int64_t st = 0;
+      for (int64_t sl = slab_ptr[2 * b]; sl < slab_ptr[2 * b + 2]; ++sl) st += (meta[sl * 64] & 0x8000) ? 1 : 0;
+      steps += st;
+      max_steps = std::max(max_steps, st);
+    }
+    for (int32_t v : slot_of) used += v >= 0;
+    fprintf(stderr, "[nsx] ilu schedule: rows %d blocks %d max_rows %d levels(max) %d LW %d slabs %lld (max/block %lld) steps %lld (max/block %lld) fill %.2f\n",
+            g.n_rows, nb, s.max_rows, s.max_levels, LW, (long long)s.n_slabs, (long long)max_slabs, (long long)steps, (long long)max_steps,
+            (double)used / (double)(s.n_slabs * 64));
+  }
+  s.pk_slab_ptr.upload(slab_ptr, h->stream);
+  s.pk_meta.upload(meta, h->stream);
+  s.pk_slot_of.upload(slot_of, h->stream);
+  s.pk_val.alloc(meta.size());
+  s.pk_val.zero(h->stream);
+  s.pk_dinv.alloc(g.n_rows);
 }
 
 void build_schur_graph(nsx_handle *h) {
@@ -159,8 +244,8 @@ static void default_ranks(nsx_handle *h) {
 static void refresh_rank_products(nsx_handle *h) {
   h->rank_u.upload(h->rank_u_h, h->stream);
   h->dbar.alloc(h->rank_u_h.size() - 1);
-  setup_ilu_schedule(h, h->gA.host, h->rank_u_h, h->schedF);
-  setup_ilu_schedule(h, h->gS.host, h->sblk_h.empty() ? h->rank_p_h : h->sblk_h, h->schedS);
+  setup_ilu_schedule(h, h->gA.host, h->rank_u_h, h->schedF, 8);
+  setup_ilu_schedule(h, h->gS.host, h->sblk_h.empty() ? h->rank_p_h : h->sblk_h, h->schedS, 32);
   h->prec_ready = false;
 }
 

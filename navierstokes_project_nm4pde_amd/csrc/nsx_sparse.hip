@@ -266,11 +266,13 @@ __global__ __launch_bounds__(ILU_WAVES * 64) void k_ilu_factor(const int32_t *__
                                                               const int32_t *__restrict__ lvl_ptr, const int32_t *__restrict__ lvl_rows,
                                                               const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
                                                               const int32_t *__restrict__ diag, const double *__restrict__ a,
-                                                              double *__restrict__ lu, int *__restrict__ err) {
+                                                              double *__restrict__ lu, const int32_t *__restrict__ slot_of,
+                                                              double *__restrict__ pk_val, double *__restrict__ pk_dinv,
+                                                              int *__restrict__ err) {
   __shared__ double wv[ILU_WAVES][ILU_MAXROW];
   const int blk = blockIdx.x, wave = threadIdx.x / 64, lane = threadIdx.x % 64;
   const int r0 = bptr[blk], r1 = bptr[blk + 1];
-  double *w = wv[wave];
+  volatile double *w = wv[wave];  // volatile: lanes of the wave exchange values through this row buffer
   for (int lv = lvl_off[blk]; lv < lvl_off[blk + 1]; ++lv) {
     const int l0 = lvl_ptr[lv], cnt = lvl_ptr[lv + 1] - l0;
     for (int r = wave; r < cnt; r += ILU_WAVES) {
@@ -313,6 +315,11 @@ __global__ __launch_bounds__(ILU_WAVES * 64) void k_ilu_factor(const int32_t *__
         if (t == dpos) v = dinv;
         else if (t > dpos) v = (j < r1) ? v * dinv : 0.0;
         lu[p0 + t] = v;
+        if (slot_of) {
+          const int sl = slot_of[p0 + t];
+          if (sl >= 0) pk_val[sl] = v;
+          if (t == dpos) pk_dinv[i] = dinv;
+        }
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -320,13 +327,14 @@ __global__ __launch_bounds__(ILU_WAVES * 64) void k_ilu_factor(const int32_t *__
   }
 }
 
-void ilu_factor(nsx_handle *h, const DevCsr &g, const IluSchedule &s, const double *vals, double *lu, const char *name) {
+void ilu_factor(nsx_handle *h, const DevCsr &g, IluSchedule &s, const double *vals, double *lu, const char *name) {
   int *err = (int *)(h->scal.p + (N_SLOTS - 1));
   HIP_CHECK(hipMemsetAsync(err, 0, sizeof(double), h->stream));
   {
     LaunchScope ls(h, name, 20.0 * g.nnz() + 12.0 * g.n_rows());
     hipLaunchKernelGGL(k_ilu_factor, dim3(s.n_blocks), dim3(ILU_WAVES * 64), 0, h->stream, s.block_ptr.p, s.blk_lvl_off.p, s.fwd_lvl_ptr.p,
-                       s.fwd_rows.p, g.rowptr.p, g.colind.p, g.diag.p, vals, lu, err);
+                       s.fwd_rows.p, g.rowptr.p, g.colind.p, g.diag.p, vals, lu, s.packed_ok ? s.pk_slot_of.p : nullptr, s.pk_val.p,
+                       s.pk_dinv.p, err);
   }
   int herr = 0;
   HIP_CHECK(hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -411,6 +419,110 @@ __global__ __launch_bounds__(256) void k_ilu_solve(const int32_t *__restrict__ b
     for (int t = threadIdx.x; t < nloc * NCOMP; t += 256) x[(size_t)r0 * NCOMP + t] = xs[t];
 }
 
+// ---- packed wave-per-block solve -------------------------------------------------------------------------------
+// One WAVE per rank block, the block's part of x in LDS, no workgroup barriers.  The factor is read as a linear
+// stream of 64-slot slabs {value, meta} laid out at setup in exactly the order the wave consumes it (nsx_setup.hip),
+// so the only dependent chain per step is LDS gather -> FMA -> LW-lane DPP reduction -> LDS update; the global loads
+// are address-independent of x and are prefetched PF slabs ahead in registers.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+template <int LW>
+__device__ __forceinline__ double lane_group_sum(double v) {
+  v += dpp_f64<0xB1>(v);                 // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);                 // quad_perm [2,3,0,1]
+  if (LW >= 8) v += dpp_f64<0x141>(v);   // row_half_mirror
+  if (LW >= 16) v += dpp_f64<0x140>(v);  // row_mirror
+  if (LW >= 32) v += __shfl_xor(v, 16, 64);
+  if (LW >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+template <int NCOMP, int LW>
+__device__ __forceinline__ void packed_slab(double v, int mk, double (&acc)[NCOMP], double *xs) {
+  const double *xj = xs + (mk & 0x7fff) * NCOMP;
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c) acc[c] += v * xj[c];
+  if (mk & 0x8000) {  // last slab of the step (wave-uniform): reduce and update the rows of this step
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) acc[c] = lane_group_sum<LW>(acc[c]);
+    const int dst = (mk >> 16) & 0xffff;
+    if (dst) {
+      double *xi = xs + (dst - 1) * NCOMP;
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) xi[c] -= acc[c];
+    }
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) acc[c] = 0.0;
+  }
+}
+
+// Two register sets (A/B) of PF slabs each: while one set is consumed the other is in flight; no register moves,
+// so hipcc can wait with a counted vmcnt on exactly the older set.
+template <int NCOMP, int LW, int PF>
+__device__ __forceinline__ void packed_sweep(int sa, int sb, const int32_t *__restrict__ meta, const double *__restrict__ val,
+                                             double *xs, int lane) {
+  double va[PF], vb[PF];
+  int ma[PF], mb[PF];
+  double acc[NCOMP];
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c) acc[c] = 0.0;
+#define NSX_LOAD(V, M, S0)                                      \
+  _Pragma("unroll") for (int k = 0; k < PF; ++k) {              \
+    const int s_ = (S0) + k;                                    \
+    const bool ok_ = s_ < sb;                                   \
+    V[k] = ok_ ? val[(size_t)s_ * 64 + lane] : 0.0;             \
+    M[k] = ok_ ? meta[(size_t)s_ * 64 + lane] : 0;              \
+  }
+#define NSX_USE(V, M, S0)                                       \
+  _Pragma("unroll") for (int k = 0; k < PF; ++k)                \
+    if ((S0) + k < sb) packed_slab<NCOMP, LW>(V[k], M[k], acc, xs);
+  NSX_LOAD(va, ma, sa)
+  for (int s0 = sa; s0 < sb; s0 += 2 * PF) {
+    NSX_LOAD(vb, mb, s0 + PF)
+    NSX_USE(va, ma, s0)
+    NSX_LOAD(va, ma, s0 + 2 * PF)
+    NSX_USE(vb, mb, s0 + PF)
+  }
+#undef NSX_LOAD
+#undef NSX_USE
+}
+
+template <int NCOMP, int LW, int PF>
+__global__ __launch_bounds__(64) void k_ilu_solve_packed(const int32_t *__restrict__ bptr, const int32_t *__restrict__ slab_ptr,
+                                                         const int32_t *__restrict__ meta, const double *__restrict__ val,
+                                                         const double *__restrict__ dinv, const double *__restrict__ b,
+                                                         double *__restrict__ x) {
+  extern __shared__ double xs[];
+  const int blk = blockIdx.x, lane = threadIdx.x;
+  const int r0 = bptr[blk], nloc = bptr[blk + 1] - r0;
+  for (int t = lane; t < nloc * NCOMP; t += 64) xs[t] = b[(size_t)r0 * NCOMP + t];
+  const int s0 = slab_ptr[2 * blk], s1 = slab_ptr[2 * blk + 1], s2 = slab_ptr[2 * blk + 2];
+  packed_sweep<NCOMP, LW, PF>(s0, s1, meta, val, xs, lane);  // y = L^{-1} b
+  for (int t = lane; t < nloc; t += 64) {                   // y *= D^{-1}
+    const double d = dinv[r0 + t];
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) xs[t * NCOMP + c] *= d;
+  }
+  packed_sweep<NCOMP, LW, PF>(s1, s2, meta, val, xs, lane);  // x = U^{-1} y
+  for (int t = lane; t < nloc * NCOMP; t += 64) x[(size_t)r0 * NCOMP + t] = xs[t];
+}
+
+template <int NCOMP, int LW>
+static void launch_packed(nsx_handle *h, const IluSchedule &s, const double *b, double *x) {
+  const size_t shm = (size_t)s.max_rows * NCOMP * sizeof(double);
+  static const int pf = getenv("NSX_PF") ? atoi(getenv("NSX_PF")) : 8;
+#define NSX_GO(PF_)                                                                                                              \
+  hipLaunchKernelGGL((k_ilu_solve_packed<NCOMP, LW, PF_>), dim3(s.n_blocks), dim3(64), shm, h->stream, s.block_ptr.p, s.pk_slab_ptr.p, \
+                     s.pk_meta.p, s.pk_val.p, s.pk_dinv.p, b, x)
+  if (pf == 4) NSX_GO(4); else if (pf == 16) NSX_GO(16); else NSX_GO(8);
+#undef NSX_GO
+}
+
 template <int NCOMP>
 static void launch_ilu_solve(nsx_handle *h, const DevCsr &g, const IluSchedule &s, const double *lu, const double *b, double *x) {
   const size_t shm = (size_t)s.max_rows * NCOMP * sizeof(double);
@@ -426,7 +538,20 @@ static void launch_ilu_solve(nsx_handle *h, const DevCsr &g, const IluSchedule &
 
 void ilu_solve(nsx_handle *h, const DevCsr &g, const IluSchedule &s, const double *lu, const double *b, double *x, int ncomp,
                const char *name) {
+  const bool packed = s.packed_ok && (size_t)s.max_rows * ncomp * sizeof(double) <= 64 * 1024;
+  // algorithmic bytes: the CSR factor once (12 B/entry) + rhs/solution vectors; the packed stream moves 768 B per slab
   LaunchScope ls(h, name, 12.0 * g.nnz() + (double)g.n_rows() * (4 + 16.0 * ncomp));
+  if (packed && (size_t)s.max_rows * ncomp * sizeof(double) <= 64 * 1024) {
+    const int lw = s.lanes_per_row;
+#define NSX_PK(NC)                                              \
+    if (lw == 8) return launch_packed<NC, 8>(h, s, b, x);       \
+    if (lw == 16) return launch_packed<NC, 16>(h, s, b, x);     \
+    if (lw == 32) return launch_packed<NC, 32>(h, s, b, x);
+    if (ncomp == 1) { NSX_PK(1) }
+    if (ncomp == 2) { NSX_PK(2) }
+    if (ncomp == 3) { NSX_PK(3) }
+#undef NSX_PK
+  }
   if (ncomp == 1) launch_ilu_solve<1>(h, g, s, lu, b, x);
   else if (ncomp == 2) launch_ilu_solve<2>(h, g, s, lu, b, x);
   else launch_ilu_solve<3>(h, g, s, lu, b, x);

@@ -34,6 +34,20 @@ else:
         dev.set_schur_blocks(d.owned_p_ptr[::step])
     inlet = InletVelocity(3)
     dev.set_solution(np.zeros(d.n_dofs))
+    if what == "ilu":
+        dev.assemble(nsx.TEMAM)
+        bd, bv = cylinder_boundary_values(d, inlet, 2e-4)
+        dev.apply_boundary_values(bd, bv)
+        dev.prec_initialize(0)
+        rng = np.random.default_rng(0)
+        xu, xp = rng.standard_normal(d.n_u), rng.standard_normal(d.n_p)
+        dev.ilu_apply(0, xu); dev.ilu_apply(1, xp)
+        dev.profile(True)
+        for _ in range(20):
+            dev.ilu_apply(0, xu); dev.ilu_apply(1, xp)
+        tab = dev.profile_table()
+        print("PF", os.environ.get("NSX_PF"), "blocks", nsub, ssub, {k: round(v["total_ms"] / v["launches"] * 1e3, 1) for k, v in tab.items()}, flush=True)
+        sys.exit(0)
     tm = 0.0
     for step in range(1, 7):
         tm += 2e-4
