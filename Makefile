@@ -11,7 +11,7 @@ HOST_SO   := $(PKG)/host/libnsx_host.so
 DEV_SO    := $(PKG)/csrc/libnsx.so
 ORACLE_SO := oracle/liboracle.so
 
-all: host oracle device
+all: host oracle device mirror
 host: $(HOST_SO)
 oracle: $(ORACLE_SO)
 device: $(DEV_SO)
@@ -27,6 +27,14 @@ DEV_HDR := $(wildcard $(PKG)/csrc/*.hpp) include/nsx.h $(PKG)/host/graph.hpp
 $(DEV_SO): $(DEV_SRC) $(DEV_HDR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(DEV_SRC) -L/opt/rocm/lib -lrccl
 
+# C++ host mirror of the reference executables (link against the in-tree libraries)
+MIRROR_BIN := $(PKG)/host/navier_stokes3D $(PKG)/host/navier_stokes2D
+mirror: $(MIRROR_BIN)
+$(PKG)/host/navier_stokes3D: $(PKG)/host/main_cylinder.cpp $(PKG)/host/NavierStokes.hpp $(HOST_SO) $(DEV_SO)
+	$(CXX) $(CXXFLAGS) -DNSX_DIM=3 -o $@ $< -L$(PKG)/host -L$(PKG)/csrc -lnsx_host -lnsx -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,'$$ORIGIN/../csrc'
+$(PKG)/host/navier_stokes2D: $(PKG)/host/main_cylinder.cpp $(PKG)/host/NavierStokes.hpp $(HOST_SO) $(DEV_SO)
+	$(CXX) $(CXXFLAGS) -DNSX_DIM=2 -o $@ $< -L$(PKG)/host -L$(PKG)/csrc -lnsx_host -lnsx -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,'$$ORIGIN/../csrc'
+
 clean:
-	rm -f $(HOST_SO) $(DEV_SO) $(ORACLE_SO)
-.PHONY: all host oracle device clean
+	rm -f $(HOST_SO) $(DEV_SO) $(ORACLE_SO) $(MIRROR_BIN)
+.PHONY: all host oracle device mirror clean

@@ -126,3 +126,116 @@ def ethier_boundary_values(dofs, exact, time):
     ds = np.unique(np.concatenate([dofs.boundary_dofs(b) for b in (0, 1, 2, 4, 5)])).astype(np.int32)
     u = exact.velocity(dofs.support_points[ds])
     return ds, u[np.arange(len(ds)), ds % 3].astype(np.float64)
+
+
+# ------------------------------------------------------------------ host-side integrals of the convergence executable
+_TET_FACES = [(0, 1, 2), (1, 0, 3), (0, 2, 3), (2, 1, 3)]
+_TRI_FACES = [(0, 1), (1, 2), (2, 0)]
+
+
+def neumann_rhs(mesh, dofs, face_tables, h_func, boundary_id=3):
+    """cell_rhs(i) += scalar_product(h, phi_i) JxW on faces with `boundary_id` (Convergence3D.cpp:309-331, 506-528).
+
+    Returns (dofs, values) with unique dofs, ready for add_rhs().  Host-side: O(boundary faces)."""
+    dim = mesh.dim
+    faces = _TET_FACES if dim == 3 else _TRI_FACES
+    nqf = face_tables.n_qf
+    acc = {}
+    sel = np.nonzero(mesh.bface_ids == boundary_id)[0]
+    for bf in sel:
+        cell = mesh.bface_cells[bf]
+        cv = mesh.cells[cell]
+        fset = set(mesh.bfaces[bf].tolist())
+        f = next(k for k, fv in enumerate(faces) if {int(cv[i]) for i in fv} == fset)
+        X = mesh.vertices[cv]
+        fx = X[list(faces[f])]
+        if dim == 3:
+            area = 0.5 * np.linalg.norm(np.cross(fx[1] - fx[0], fx[2] - fx[0]))
+        else:
+            area = np.linalg.norm(fx[1] - fx[0])
+        q = slice(f * nqf, (f + 1) * nqf)
+        xh = face_tables.points[q]
+        xp = X[0] + xh @ (X[1:] - X[0])
+        hv = h_func(xp)                      # [nqf, dim]
+        N = face_tables.N2[q]                # [nqf, n_p2]
+        w = face_tables.weights[q] * area
+        loc = np.einsum("q,qa,qc->ac", w, N, hv)   # [n_p2, dim]
+        cd = dofs.cell_dofs[cell]
+        nv = dim + 1
+        for a in range(N.shape[1]):
+            base = (dim + 1) * a if a < nv else nv * (dim + 1) + dim * (a - nv)
+            for c in range(dim):
+                d = int(cd[base + c])
+                acc[d] = acc.get(d, 0.0) + loc[a, c]
+    keys = np.array(sorted(acc), dtype=np.int32)
+    return keys, np.array([acc[k] for k in keys.tolist()])
+
+
+def velocity_error(mesh, dofs, solution, exact, tables_high, norm="L2"):
+    """VectorTools::integrate_difference with the velocity mask + compute_global_error (Convergence3D.cpp:766-794)."""
+    dim = mesh.dim
+    nv = dim + 1
+    X = mesh.vertices[mesh.cells]                        # [nc, nv, dim]
+    J = np.transpose(X[:, 1:] - X[:, :1], (0, 2, 1))     # [nc, dim(d), dim(k)] : J[d][k]
+    detJ = np.abs(np.linalg.det(J))
+    Jinv = np.linalg.inv(J)
+    np2 = tables_high.n_p2
+    vel_base = [(dim + 1) * a if a < nv else nv * (dim + 1) + dim * (a - nv) for a in range(np2)]
+    U = np.stack([solution[dofs.cell_dofs[:, [b + c for b in vel_base]]] for c in range(dim)], axis=2)  # [nc, np2, dim]
+    N, dN, w = tables_high.N2, tables_high.dN2, tables_high.weights
+    xq = X[:, :1] + np.einsum("qk,ckd->cqd", tables_high.points, X[:, 1:] - X[:, :1])   # [nc, nq, dim]
+    uh = np.einsum("qa,cac->cqc", N, U) if False else np.einsum("qa,cad->cqd", N, U)
+    nc, nq = xq.shape[0], xq.shape[1]
+    ue = exact.velocity(xq.reshape(-1, dim)).reshape(nc, nq, dim)
+    err2 = np.einsum("cq,cqd->", detJ[:, None] * w[None, :], (uh - ue) ** 2)
+    if norm == "H1":
+        gphys = np.einsum("ckd,qak->cqad", Jinv, dN)       # d N_a / d x_d = sum_k Jinv[k][d] dNhat[k]
+        guh = np.einsum("cqad,cai->cqid", gphys, U)        # d u_i / d x_d
+        ge = exact.gradient(xq.reshape(-1, dim)).reshape(nc, nq, dim, dim)
+        err2 += np.einsum("cq,cqid->", detJ[:, None] * w[None, :], (guh - ge) ** 2)
+    return float(np.sqrt(err2))
+
+
+def run_convergence_case(backend_factory, n, prec=0, tol_abs=1e-4, inner_rtol=1e-2, T=3e-4, deltat=4e-4, nu=1e-2):
+    """One run of the `convergence` executable on the cube with n cells per side
+    (main_convergence3D.cpp:35-52, Convergence3D.cpp:726-764).  `backend_factory(dofs, tables, nu, dt)` returns an
+    object with the assemble / add_rhs / apply_boundary_values / solve_time_step / solution interface
+    (oracle.Oracle or nsx.Nsx).  Reference quirks kept: Neumann datum evaluated at t_n (Conv:747-750), convection
+    assembled twice in the first step (Conv:277,284), error evaluated with the exact solution at T = 3e-4 while the
+    state is at t = 4e-4 (Conv:774)."""
+    from .frontend import DoFs, Mesh, Tables
+    mesh = Mesh.cube(n)
+    dofs, tables = DoFs(mesh), Tables(3)
+    ftab, htab = Tables(3, Tables.FACE), Tables(3, Tables.HIGH, 5)
+    ex = EthierSteinmann(nu)
+    be = backend_factory(dofs, tables, nu, deltat)
+    X = dofs.support_points
+    u0 = np.zeros(dofs.n_dofs)
+    ex.set_time(0.0)
+    vel = ex.velocity(X[:dofs.n_u])
+    u0[:dofs.n_u] = vel[np.arange(dofs.n_u), np.arange(dofs.n_u) % 3]
+    u0[dofs.n_u:] = ex.pressure(X[dofs.n_u:])          # VectorTools::interpolate(dof_handler, u_0, ...) (Conv:735)
+    if hasattr(be, "set_solution"):
+        be.set_solution(u0)
+    else:
+        be.solution[:] = u0
+        be.solution_owned[:] = u0
+    time, step = 0.0, 0
+    stats = None
+    while time < T - 0.5 * deltat:
+        ex.set_time(time)                               # function_h.set_time(time) BEFORE the increment (Conv:747-750)
+        hd, hv = neumann_rhs(mesh, dofs, ftab, ex.neumann_h, 3)
+        time += deltat
+        step += 1
+        if step == 1:
+            be.assemble(1 | 2)                          # TEMAM | DOUBLE_CONVECTION
+        else:
+            be.assemble_time_step(1)
+        be.add_rhs(hd, hv)
+        bd, bv = ethier_boundary_values(dofs, ex, time)
+        be.apply_boundary_values(bd, bv)
+        stats = be.solve_time_step(prec, tol_abs=tol_abs, inner_rtol=inner_rtol)
+    sol = np.array(be.solution)
+    ex.set_time(T)
+    return {"h": 1.0 / (n / 2.0) / 1.0, "L2": velocity_error(mesh, dofs, sol, ex, htab, "L2"),
+            "H1": velocity_error(mesh, dofs, sol, ex, htab, "H1"), "stats": stats, "n_dofs": dofs.n_dofs, "solution": sol}
