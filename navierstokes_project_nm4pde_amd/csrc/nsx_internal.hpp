@@ -122,6 +122,8 @@ struct ProfEntry {
 
 struct Comm;  // RCCL state (nsx_comm.hip)
 
+enum { N_SLOTS = 128 };  // device scalar slots (reduction results)
+
 }  // namespace nsx
 
 struct nsx_handle {
@@ -161,6 +163,7 @@ struct nsx_handle {
   std::vector<nsx::DevBuf<double> *> pool;  // temporary vectors handed out by size
   nsx::DevBuf<double> red_partial;          // reduction partials
   nsx::DevBuf<double> scal;                 // device scalars
+  int slot_nb[nsx::N_SLOTS] = {0};          // >0: the slot's value is still spread over that many partial sums
   double *scal_host = nullptr;              // pinned mirror
   // ---- profiling
   bool prof_on = false;
@@ -217,7 +220,6 @@ void extract_diag(nsx_handle *h, const DevCsr &g, const double *vals, double *d)
 void abs_rowsum(nsx_handle *h, const DevCsr &g, const double *vals, double *d);
 
 // BLAS-1 (nsx_blas.hip): scalars live in h->scal[slot]
-enum { N_SLOTS = 128 };
 void v_copy(nsx_handle *h, int n, double *d, const double *s);
 void v_zero(nsx_handle *h, int n, double *d);
 void v_add(nsx_handle *h, int n, double *d, double a, const double *v);                     // d += a v
@@ -230,6 +232,7 @@ void v_dot(nsx_handle *h, int n, const double *a, const double *b, int slot);   
 void v_add_and_dot(nsx_handle *h, int n, double *d, double a, int aslot, const double *v, const double *w, int slot);
                                                                                             // d += a*scal[aslot]*v ; scal[slot] = d.w
 void v_axpy_multi(nsx_handle *h, int n, double *x, int k, double *const *vs, const double *coef_host);
+void finalize_slots(nsx_handle *h, int slot0, int count);
 double read_scalar(nsx_handle *h, int slot);
 void read_scalars(nsx_handle *h, int slot0, int count, double *out);
 void write_scalar(nsx_handle *h, int slot, double v);

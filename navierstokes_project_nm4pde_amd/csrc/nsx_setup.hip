@@ -244,8 +244,9 @@ static void default_ranks(nsx_handle *h) {
 static void refresh_rank_products(nsx_handle *h) {
   h->rank_u.upload(h->rank_u_h, h->stream);
   h->dbar.alloc(h->rank_u_h.size() - 1);
-  setup_ilu_schedule(h, h->gA.host, h->rank_u_h, h->schedF, 8);
-  setup_ilu_schedule(h, h->gS.host, h->sblk_h.empty() ? h->rank_p_h : h->sblk_h, h->schedS, 32);
+  const int lwF = getenv("NSX_LW_F") ? atoi(getenv("NSX_LW_F")) : 16, lwS = getenv("NSX_LW_S") ? atoi(getenv("NSX_LW_S")) : 32;
+  setup_ilu_schedule(h, h->gA.host, h->rank_u_h, h->schedF, lwF);
+  setup_ilu_schedule(h, h->gS.host, h->sblk_h.empty() ? h->rank_p_h : h->sblk_h, h->schedS, lwS);
   h->prec_ready = false;
 }
 

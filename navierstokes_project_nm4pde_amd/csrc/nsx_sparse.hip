@@ -13,11 +13,28 @@
 
 namespace nsx {
 
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+template <int LW>
+__device__ __forceinline__ double lane_group_sum(double v) {
+  if (LW >= 2) v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+  if (LW >= 4) v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+  if (LW >= 8) v += dpp_f64<0x141>(v);   // row_half_mirror
+  if (LW >= 16) v += dpp_f64<0x140>(v);  // row_mirror
+  if (LW >= 32) v += __shfl_xor(v, 16, 64);
+  if (LW >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+// sum over the W lanes of a row group, result in every lane: DPP (pure VALU) up to 16 lanes, then cross-row shuffles
 template <int W>
 __device__ __forceinline__ double group_sum(double v) {
-#pragma unroll
-  for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, W);
-  return v;
+  return lane_group_sum<W>(v);
 }
 
 // ------------------------------------------------------------------ SpMV
@@ -28,7 +45,11 @@ __global__ __launch_bounds__(256) void k_spmv_vel(int n_rows, const int32_t *__r
                                                   const int32_t *__restrict__ grp, const int32_t *__restrict__ gci,
                                                   const double *__restrict__ gv, const double *__restrict__ xp,
                                                   double *__restrict__ y) {
-  const int row = (blockIdx.x * 256 + threadIdx.x) / W, lane = threadIdx.x % W;
+  // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs, so give XCD k the k-th contiguous eighth of the
+  // rows: the x entries a row gathers are then shared inside one 4-MiB L2 instead of being fetched into all eight
+  // (grid is a multiple of 8; speed only, any placement is correct).
+  const int bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int row = (bid * 256 + threadIdx.x) / W, lane = threadIdx.x % W;
   if (row >= n_rows) return;  // whole groups exit together
   double acc[DIM];
 #pragma unroll
@@ -122,13 +143,16 @@ static double bytes_vel(nsx_handle *h, bool with_g) {
 
 void spmv_F(nsx_handle *h, const double *vals, const double *x, double *y) {
   LaunchScope ls(h, "spmv_F", bytes_vel(h, false));
-  const int W = 16, grid = cdiv((int64_t)h->N2 * W, 256);
-  if (h->dim == 2)
-    hipLaunchKernelGGL((k_spmv_vel<2, W, false>), dim3(grid), dim3(256), 0, h->stream, h->N2, h->gA.rowptr.p, h->gA.colind.p, vals, x,
-                       nullptr, nullptr, nullptr, nullptr, y);
-  else
-    hipLaunchKernelGGL((k_spmv_vel<3, W, false>), dim3(grid), dim3(256), 0, h->stream, h->N2, h->gA.rowptr.p, h->gA.colind.p, vals, x,
-                       nullptr, nullptr, nullptr, nullptr, y);
+  static const int Wsel = getenv("NSX_SPMV_W") ? atoi(getenv("NSX_SPMV_W")) : 16;
+#define NSX_SPMV(D, W_)                                                                                                          \
+  hipLaunchKernelGGL((k_spmv_vel<D, W_, false>), dim3((cdiv((int64_t)h->N2 * W_, 256) + 7) & ~7), dim3(256), 0, h->stream, h->N2, \
+                     h->gA.rowptr.p, h->gA.colind.p, vals, x, nullptr, nullptr, nullptr, nullptr, y)
+  if (h->dim == 2) {
+    if (Wsel == 8) NSX_SPMV(2, 8); else if (Wsel == 32) NSX_SPMV(2, 32); else NSX_SPMV(2, 16);
+  } else {
+    if (Wsel == 8) NSX_SPMV(3, 8); else if (Wsel == 32) NSX_SPMV(3, 32); else NSX_SPMV(3, 16);
+  }
+#undef NSX_SPMV
 }
 
 void spmv_B(nsx_handle *h, const double *xu, double *yp) {
@@ -156,7 +180,7 @@ void spmv_G(nsx_handle *h, const double *xp, double *yu, bool accumulate) {
 void spmv_saddle(nsx_handle *h, const double *x, double *y) {
   {
     LaunchScope ls(h, "spmv_saddle_u", bytes_vel(h, true));
-    const int W = 16, grid = cdiv((int64_t)h->N2 * W, 256);
+    const int W = 16, grid = (cdiv((int64_t)h->N2 * W, 256) + 7) & ~7;
     if (h->dim == 2)
       hipLaunchKernelGGL((k_spmv_vel<2, W, true>), dim3(grid), dim3(256), 0, h->stream, h->N2, h->gA.rowptr.p, h->gA.colind.p, h->vF.p, x,
                          h->gG.rowptr.p, h->gG.colind.p, h->vG.p, x + h->n_u, y);
@@ -424,24 +448,6 @@ __global__ __launch_bounds__(256) void k_ilu_solve(const int32_t *__restrict__ b
 // stream of 64-slot slabs {value, meta} laid out at setup in exactly the order the wave consumes it (nsx_setup.hip),
 // so the only dependent chain per step is LDS gather -> FMA -> LW-lane DPP reduction -> LDS update; the global loads
 // are address-independent of x and are prefetched PF slabs ahead in registers.
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
-  return __hiloint2double(hi, lo);
-}
-template <int LW>
-__device__ __forceinline__ double lane_group_sum(double v) {
-  v += dpp_f64<0xB1>(v);                 // quad_perm [1,0,3,2]
-  v += dpp_f64<0x4E>(v);                 // quad_perm [2,3,0,1]
-  if (LW >= 8) v += dpp_f64<0x141>(v);   // row_half_mirror
-  if (LW >= 16) v += dpp_f64<0x140>(v);  // row_mirror
-  if (LW >= 32) v += __shfl_xor(v, 16, 64);
-  if (LW >= 64) v += __shfl_xor(v, 32, 64);
-  return v;
-}
-
 template <int NCOMP, int LW>
 __device__ __forceinline__ void packed_slab(double v, int mk, double (&acc)[NCOMP], double *xs) {
   const double *xj = xs + (mk & 0x7fff) * NCOMP;
