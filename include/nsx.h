@@ -163,13 +163,31 @@ int nsx_profile_count(nsx_handle *h);
 int nsx_profile_get(nsx_handle *h, int i, const char **name, int64_t *launches, double *total_ms, double *bytes_per_launch);
 
 /* ---- multi-GPU (one process per GPU, RCCL over xGMI) ---- */
+/* Replaces the MPI communicator inside Epetra (reference NavierStokes3D.hpp:93-94,102): MPI_Allreduce behind every
+ * dot / norm, Epetra_Import behind every vmult and behind `solution = solution_owned` (NavierStokes3D.cpp:638). */
 int nsx_comm_unique_id(uint8_t id[128]);                       /* rank 0: ncclGetUniqueId */
-int nsx_comm_init(nsx_handle *h, int rank, int world, const uint8_t id[128]);
-/* Distributed mesh: this rank's cells (owned + one ghost layer) in GLOBAL dof numbering plus the global
- * ownership ranges of all ranks; replaces nsx_set_mesh + nsx_set_ranks for world > 1. */
-int nsx_set_mesh_distributed(nsx_handle *h, int n_cells, int dofs_per_cell, const int32_t *cell_dofs,
-                             const double *cell_coords, int n_u_global, int n_p_global, int world,
-                             const int32_t *gpu_u_ptr, const int32_t *gpu_p_ptr);
+int nsx_comm_init(nsx_handle *h, int rank, int world, const uint8_t id[128]);   /* RCCL over xGMI */
+/* Bring-your-own communicator (the reference's MPI, gloo in the tests): host-buffer callbacks, return 0 on success.
+ * allreduce: in-place sum of `count` doubles over all ranks.  exchange: for each of n neighbours send send[k]
+ * (send_count[k] doubles) to rank ranks[k] and receive recv_count[k] doubles from it into recv[k]. */
+typedef int (*nsx_allreduce_fn)(void *ctx, double *buf, int count);
+typedef int (*nsx_exchange_fn)(void *ctx, int n, const int *ranks, const double *const *send, const int *send_count,
+                               double *const *recv, const int *recv_count);
+int nsx_comm_init_callbacks(nsx_handle *h, int rank, int world, nsx_allreduce_fn allreduce, nsx_exchange_fn exchange, void *ctx);
+/* Distributed mesh, replaces nsx_set_mesh for world > 1.  cell_dofs keep the GLOBAL deal.II numbering; gpu_u_ptr /
+ * gpu_p_ptr [world+1] are the P2 / P1 node ranges owned by each rank (locally_owned_dofs per block, reference
+ * NavierStokes3D.cpp:71-87).  Cells: first the n_cells_layer1 cells that touch an owned P2 node (every owned row is
+ * assembled locally, no compress(VectorOperation::add), NavierStokes3D.cpp:314-319), then the cells touching a node
+ * of those (rows of block(1,0) for the ghost pressure nodes the Schur product reaches).  Halo plan: for each
+ * neighbour (ascending ranks) the global ids of the owned nodes it needs, ascending (include/nsx_host.h:
+ * nsxh_rank_view_*).  Afterwards nsx_set_ranks takes GLOBAL node ranges of this rank's sub-blocks; state vectors
+ * (nsx_set_solution, nsx_get_*, nsx_apply_boundary_values, nsx_system_vmult) are indexed GLOBALLY, get_* fill only the
+ * entries this rank owns. */
+int nsx_set_mesh_distributed(nsx_handle *h, int n_cells, int n_cells_layer1, int dofs_per_cell, const int32_t *cell_dofs,
+                             const double *cell_coords, int n_u_global, int n_p_global, int world, int rank,
+                             const int32_t *gpu_u_ptr, const int32_t *gpu_p_ptr, int n_neighbors, const int32_t *neighbors,
+                             const int32_t *send_u_ptr, const int32_t *send_u_nodes, const int32_t *send_p_ptr,
+                             const int32_t *send_p_nodes);
 
 #ifdef __cplusplus
 }

@@ -93,6 +93,32 @@ int nsxh_boundary_dofs(nsxh_dofs *, int boundary_id, const int32_t **dofs);
  * 3 = pressure-mass (1,1) n_p x n_p (:127-142). CSR with sorted columns. */
 int nsxh_reference_sparsity(nsxh_dofs *, int block, const int32_t **rowptr, const int32_t **colind);
 
+/* ---- per-rank view for multi-GPU runs (one process per GPU; GPU r = subdomains [r*n_sub, (r+1)*n_sub)) ----
+ * Cells: layer 1 = every cell touching an owned P2 node (all owned matrix rows assemble without exchange, replacing
+ * compress(VectorOperation::add), reference NavierStokes3D.cpp:314-319,506-511), then layer 2 = cells touching a node
+ * of layer 1 (completes the block(1,0) rows the Schur product of an owned row reaches).  cell_dofs keep GLOBAL indices.
+ * Halo plan (the Epetra_Import of every vmult): for each neighbour the owned P2 / P1 nodes it needs, sorted by global
+ * id; it is computed from the replicated serial mesh like the reference's partition (NavierStokes3D.cpp:8-19). */
+typedef struct nsxh_rank_view nsxh_rank_view;
+nsxh_rank_view *nsxh_rank_view_create(const nsxh_dofs *, int rank, int world);
+void nsxh_rank_view_free(nsxh_rank_view *);
+int nsxh_rank_view_n_cells(const nsxh_rank_view *);
+int nsxh_rank_view_n_cells_layer1(const nsxh_rank_view *);
+const int32_t *nsxh_rank_view_cell_ids(const nsxh_rank_view *);      /* [n_cells] global cell ids */
+const int32_t *nsxh_rank_view_cell_dofs(const nsxh_rank_view *);     /* [n_cells][dofs_per_cell] global dofs */
+const double *nsxh_rank_view_cell_coords(const nsxh_rank_view *);
+const int32_t *nsxh_rank_view_gpu_u_ptr(const nsxh_rank_view *);     /* [world+1] P2-node ranges of the GPUs */
+const int32_t *nsxh_rank_view_gpu_p_ptr(const nsxh_rank_view *);
+int nsxh_rank_view_n_virtual_ranks(const nsxh_rank_view *);          /* n_sub */
+const int32_t *nsxh_rank_view_rank_u_ptr(const nsxh_rank_view *);    /* [n_sub+1] global P2-node ranges of this GPU's subdomains */
+const int32_t *nsxh_rank_view_rank_p_ptr(const nsxh_rank_view *);
+int nsxh_rank_view_n_neighbors(const nsxh_rank_view *);
+const int32_t *nsxh_rank_view_neighbors(const nsxh_rank_view *);     /* [n_neighbors] ascending ranks */
+const int32_t *nsxh_rank_view_send_u_ptr(const nsxh_rank_view *);    /* [n_neighbors+1] */
+const int32_t *nsxh_rank_view_send_u_nodes(const nsxh_rank_view *);  /* global P2 node ids */
+const int32_t *nsxh_rank_view_send_p_ptr(const nsxh_rank_view *);
+const int32_t *nsxh_rank_view_send_p_nodes(const nsxh_rank_view *);
+
 /* ---- reference-element tables (what FEValues evaluates once per run) ---- */
 
 /* rule: 0 = cell rule QGaussSimplex<dim>(3) stand-in (degree 5: 7 pts in 2D, 14 pts in 3D; see DESIGN.md note Q),

@@ -26,14 +26,14 @@ namespace nsx {
 // wave-uniform (scalar) loads of one loop body are contiguous.  The b loop is kept rolled and its table pointers are made opaque
 // per iteration: otherwise hipcc hoists all 560 table values into SGPRs and spills them into 256 VGPRs (occupancy 1).
 template <int DIM, int NP2, int NQ, bool TEMAM>
-__global__ __launch_bounds__(64) void k_cell_convection(int n_cells, const int32_t *__restrict__ cell_n2,
+__global__ __launch_bounds__(64) void k_cell_convection(int n_active, int n_cells, const int32_t *__restrict__ cell_n2,
                                                         const double *__restrict__ geo, const double *__restrict__ tN,
                                                         const double *__restrict__ tdN, const double *__restrict__ tNT,
                                                         const double *__restrict__ tdNT, const double *__restrict__ tw,
                                                         const double *__restrict__ sol, double conv_scale,
                                                         double *__restrict__ cellbuf) {
   const int cell = blockIdx.x * 64 + threadIdx.x;
-  if (cell >= n_cells) return;
+  if (cell >= n_active) return;  // n_active = cells touching an owned node; n_cells = SoA plane stride
   double Ji[DIM][DIM];
 #pragma unroll
   for (int k = 0; k < DIM; ++k)
@@ -255,15 +255,17 @@ __global__ void k_add_rhs(int n, const int32_t *dofs, const double *vals, double
 // ------------------------------------------------------------------ host drivers
 template <int DIM, int NP2, int NQ>
 static void launch_conv(nsx_handle *h, bool temam, double conv_scale) {
-  const int grid = cdiv(h->n_cells, 64);
-  const double bytes = (double)h->n_cells * (4.0 * NP2 + 8.0 * (DIM * DIM + 1) + 8.0 * DIM * NP2 + 8.0 * NP2 * NP2);
+  const int grid = cdiv(h->n_cells1, 64);
+  const double bytes = (double)h->n_cells1 * (4.0 * NP2 + 8.0 * (DIM * DIM + 1) + 8.0 * DIM * NP2 + 8.0 * NP2 * NP2);
   LaunchScope ls(h, "cell_convection", bytes);
   if (temam)
-    hipLaunchKernelGGL((k_cell_convection<DIM, NP2, NQ, true>), dim3(grid), dim3(64), 0, h->stream, h->n_cells, h->cell_n2.p,
-                       h->geo.p, h->tab_N2.p, h->tab_dN2.p, h->tab_N2T.p, h->tab_dN2T.p, h->tab_w.p, h->sol.p, conv_scale, h->cellbuf.p);
+    hipLaunchKernelGGL((k_cell_convection<DIM, NP2, NQ, true>), dim3(grid), dim3(64), 0, h->stream, h->n_cells1, h->n_cells,
+                       h->cell_n2.p, h->geo.p, h->tab_N2.p, h->tab_dN2.p, h->tab_N2T.p, h->tab_dN2T.p, h->tab_w.p, h->sol.p, conv_scale,
+                       h->cellbuf.p);
   else
-    hipLaunchKernelGGL((k_cell_convection<DIM, NP2, NQ, false>), dim3(grid), dim3(64), 0, h->stream, h->n_cells, h->cell_n2.p,
-                       h->geo.p, h->tab_N2.p, h->tab_dN2.p, h->tab_N2T.p, h->tab_dN2T.p, h->tab_w.p, h->sol.p, conv_scale, h->cellbuf.p);
+    hipLaunchKernelGGL((k_cell_convection<DIM, NP2, NQ, false>), dim3(grid), dim3(64), 0, h->stream, h->n_cells1, h->n_cells,
+                       h->cell_n2.p, h->geo.p, h->tab_N2.p, h->tab_dN2.p, h->tab_N2T.p, h->tab_dN2T.p, h->tab_w.p, h->sol.p, conv_scale,
+                       h->cellbuf.p);
 }
 
 static void dispatch_conv(nsx_handle *h, bool temam, double conv_scale) {
@@ -331,7 +333,7 @@ void run_assemble(nsx_handle *h, bool first, int flags) {
     }
     launch_static(h, 3);
     gather<1>(h, "gather_static", h->gmPM, h->cellbuf.p, 1.0, nullptr, h->vPM.p, nullptr);
-    hipLaunchKernelGGL(k_fill, dim3(cdiv(h->n_u, 256)), dim3(256), 0, h->stream, (int64_t)h->n_u, h->dirmask.p, 1.0);
+    hipLaunchKernelGGL(k_fill, dim3(cdiv(h->len_u, 256)), dim3(256), 0, h->stream, (int64_t)h->len_u, h->dirmask.p, 1.0);
     // S0 = M + K is formed below together with F (k_add3)
   }
   const double conv_scale = (first && (flags & NSX_DOUBLE_CONVECTION)) ? 2.0 : 1.0;
@@ -348,32 +350,42 @@ void run_assemble(nsx_handle *h, bool first, int flags) {
   // rhs (NS3D.cpp:269,459): rhs_i = sum_q (u_n . phi_i) JxW / dt = (mass_matrix * u_n)_i since u_n = sum_j U_j phi_j;
   // one SpMV with the stored M/dt replaces a second per-cell scatter.  Pressure part is zero (NS3D.cpp:195,396).
   spmv_F(h, h->vMass.p, h->sol.p, h->rhs.p);
-  HIP_CHECK(hipMemsetAsync(h->rhs.p + h->n_u, 0, (size_t)h->n_p * sizeof(double), h->stream));
+  HIP_CHECK(hipMemsetAsync(h->rhs.p + h->off_p, 0, (size_t)h->n_p * sizeof(double), h->stream));
   HIP_CHECK(hipGetLastError());
   h->assembled = true;
   h->prec_ready = false;
 }
 
-void run_dirichlet(nsx_handle *h, int n, const int32_t *dofs, const double *vals) {
+void run_dirichlet(nsx_handle *h, int n_in, const int32_t *dofs_in, const double *vals_in) {
   if (!h->assembled) NSX_THROW(NSX_ERR_ARG, "assemble before applying boundary values");
   HIP_CHECK(hipSetDevice(h->prm.device));
   const int dim = h->dim;
-  if (n < 0 || (n > 0 && (!dofs || !vals))) NSX_THROW(NSX_ERR_ARG, "bad boundary value arrays");
-  // validate the map once per distinct dof list: sorted, velocity dofs only, whole nodes
-  if ((int)h->bc_cache.size() != n || (n > 0 && memcmp(h->bc_cache.data(), dofs, (size_t)n * sizeof(int32_t)) != 0)) {
-    if (n % dim) NSX_THROW(NSX_ERR_UNSUPPORTED, "boundary map must constrain all %d velocity components of a node", dim);
-    for (int k = 0; k < n; ++k) {
-      if (dofs[k] < 0 || dofs[k] >= h->n_u) NSX_THROW(NSX_ERR_UNSUPPORTED, "only velocity dofs can be constrained (dof %d)", dofs[k]);
-      if (k > 0 && dofs[k] <= dofs[k - 1]) NSX_THROW(NSX_ERR_ARG, "boundary map must be sorted by dof (std::map order)");
-      if (k % dim == 0 ? dofs[k] % dim != 0 : dofs[k] != dofs[k - 1] + 1)
-        NSX_THROW(NSX_ERR_UNSUPPORTED, "boundary map must constrain all %d velocity components of a node (dof %d)", dim, dofs[k]);
+  if (n_in < 0 || (n_in > 0 && (!dofs_in || !vals_in))) NSX_THROW(NSX_ERR_ARG, "bad boundary value arrays");
+  // the map uses global dofs; a rank applies the entries it owns (MatrixTools::apply_boundary_values does the same per rank)
+  std::vector<int32_t> dofs;
+  std::vector<double> vals;
+  const int32_t lo = dim * h->goff_u, hi = lo + h->n_u;
+  for (int k = 0; k < n_in; ++k) {
+    if (dofs_in[k] < 0 || dofs_in[k] >= h->n_u_glob) NSX_THROW(NSX_ERR_UNSUPPORTED, "only velocity dofs can be constrained (dof %d)", dofs_in[k]);
+    if (k > 0 && dofs_in[k] <= dofs_in[k - 1]) NSX_THROW(NSX_ERR_ARG, "boundary map must be sorted by dof (std::map order)");
+    if (dofs_in[k] >= lo && dofs_in[k] < hi) {
+      dofs.push_back(dofs_in[k] - lo);
+      vals.push_back(vals_in[k]);
     }
-    h->bc_cache.assign(dofs, dofs + n);
+  }
+  const int n = (int)dofs.size();
+  // validate the map once per distinct dof list: whole nodes only
+  if (h->bc_cache != dofs) {
+    if (n % dim) NSX_THROW(NSX_ERR_UNSUPPORTED, "boundary map must constrain all %d velocity components of a node", dim);
+    for (int k = 0; k < n; ++k)
+      if (k % dim == 0 ? dofs[k] % dim != 0 : dofs[k] != dofs[k - 1] + 1)
+        NSX_THROW(NSX_ERR_UNSUPPORTED, "boundary map must constrain all %d velocity components of a node (dof %d)", dim, dofs[k] + lo);
+    h->bc_cache = dofs;
     h->bc_dofs.alloc(n);
     h->bc_vals.alloc(n);
-    if (n) HIP_CHECK(hipMemcpyAsync(h->bc_dofs.p, dofs, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    if (n) HIP_CHECK(hipMemcpyAsync(h->bc_dofs.p, dofs.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
   }
-  if (n) HIP_CHECK(hipMemcpyAsync(h->bc_vals.p, vals, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (n) HIP_CHECK(hipMemcpyAsync(h->bc_vals.p, vals.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
   const int nr = (int)h->rank_u_h.size() - 1;
   {
     LaunchScope ls(h, "dirichlet", 0);
@@ -389,6 +401,7 @@ void run_dirichlet(nsx_handle *h, int n, const int32_t *dofs, const double *vals
   }
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipStreamSynchronize(h->stream));  // host arrays are borrowed for the call only
+  comm_halo_u(h, h->dirmask.p);                // the Schur weights need the mask of ghost dofs too
   h->prec_ready = false;
 }
 
@@ -419,11 +432,23 @@ int nsx_add_rhs(nsx_handle *h, int n, const int32_t *dofs, const double *vals) {
     if (!h->assembled) NSX_THROW(NSX_ERR_ARG, "assemble first");
     if (n < 0 || (n && (!dofs || !vals))) NSX_THROW(NSX_ERR_ARG, "bad arrays");
     HIP_CHECK(hipSetDevice(h->prm.device));
+    std::vector<int32_t> ld;  // global dofs -> local owned positions
+    std::vector<double> lv;
+    for (int k = 0; k < n; ++k) {
+      const int32_t g = dofs[k];
+      if (g < h->n_u_glob) {
+        if (g >= h->dim * h->goff_u && g < h->dim * h->goff_u + h->n_u) { ld.push_back(g - h->dim * h->goff_u); lv.push_back(vals[k]); }
+      } else if (g - h->n_u_glob >= h->goff_p && g - h->n_u_glob < h->goff_p + h->n_p) {
+        ld.push_back(h->off_p + g - h->n_u_glob - h->goff_p);
+        lv.push_back(vals[k]);
+      }
+    }
+    const int m = (int)ld.size();
     nsx::DevBuf<int32_t> d;
     nsx::DevBuf<double> v;
-    d.upload(dofs, n, h->stream);
-    v.upload(vals, n, h->stream);
-    if (n) hipLaunchKernelGGL(nsx::k_add_rhs, dim3(nsx::cdiv(n, 256)), dim3(256), 0, h->stream, n, d.p, v.p, h->rhs.p);
+    d.upload(ld.data(), m, h->stream);
+    v.upload(lv.data(), m, h->stream);
+    if (m) hipLaunchKernelGGL(nsx::k_add_rhs, dim3(nsx::cdiv(m, 256)), dim3(256), 0, h->stream, m, d.p, v.p, h->rhs.p);
     HIP_CHECK(hipStreamSynchronize(h->stream));
   })
 }

@@ -71,7 +71,7 @@ __device__ __forceinline__ double block_sum_256(double v, double *sh) {
 // d (+)= alpha v ; partial[b] = sum_i d_i * w_i over the block's fixed slice
 enum { OP_DOT = 0, OP_ADD_AND_DOT = 1 };
 template <int OP>
-__global__ __launch_bounds__(256) void k_reduce(int n, double *__restrict__ d, SRef a, const double *__restrict__ v,
+__global__ __launch_bounds__(256) void k_reduce(int n, int split, int gap, double *__restrict__ d, SRef a, const double *__restrict__ v,
                                                 const double *__restrict__ w, const double *__restrict__ scal,
                                                 const double *__restrict__ partial_in, double *__restrict__ partial) {
   __shared__ double sh[5];
@@ -79,7 +79,8 @@ __global__ __launch_bounds__(256) void k_reduce(int n, double *__restrict__ d, S
   const double alpha = OP == OP_ADD_AND_DOT ? sval(scal, partial_in, a, sh + 4) : 0.0;
   const bool self = (w == d);
 #pragma unroll 4
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+  for (int i0 = blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += gridDim.x * 256) {
+    const int i = i0 + (i0 >= split ? gap : 0);
     double di = d[i];
     if (OP == OP_ADD_AND_DOT) {
       di += alpha * v[i];
@@ -132,30 +133,33 @@ static double *red_out(nsx_handle *h, int slot, int nb) {
   return nb > 1 ? h->red_partial.p + (size_t)slot * RED_STRIDE : h->scal.p + slot;
 }
 
-void v_dot(nsx_handle *h, int n, const double *a, const double *b, int slot) {
+void v_dot(nsx_handle *h, Span sp, const double *a, const double *b, int slot) {
+  const int n = sp.n;
   LaunchScope ls(h, "dot", (a == b ? 8.0 : 16.0) * n);
   const int nb = red_blocks(n);
-  hipLaunchKernelGGL((k_reduce<OP_DOT>), dim3(nb), dim3(256), 0, h->stream, n, const_cast<double *>(a), SRef{0, -1, -1, 0, 0}, nullptr, b,
+  hipLaunchKernelGGL((k_reduce<OP_DOT>), dim3(nb), dim3(256), 0, h->stream, n, sp.split, sp.gap, const_cast<double *>(a), SRef{0, -1, -1, 0, 0}, nullptr, b,
                      h->scal.p, h->red_partial.p, red_out(h, slot, nb));
   after_reduction(h, slot, nb);
 }
 
-void v_add_and_dot(nsx_handle *h, int n, double *d, double a, int aslot, const double *v, const double *w, int slot) {
+void v_add_and_dot(nsx_handle *h, Span sp, double *d, double a, int aslot, const double *v, const double *w, int slot) {
+  const int n = sp.n;
   LaunchScope ls(h, "add_and_dot", (w == d ? 24.0 : 32.0) * n);
   const int nb = red_blocks(n);
-  hipLaunchKernelGGL((k_reduce<OP_ADD_AND_DOT>), dim3(nb), dim3(256), 0, h->stream, n, d, sref(h, a, aslot, -1), v, w, h->scal.p,
+  hipLaunchKernelGGL((k_reduce<OP_ADD_AND_DOT>), dim3(nb), dim3(256), 0, h->stream, n, sp.split, sp.gap, d, sref(h, a, aslot, -1), v, w, h->scal.p,
                      h->red_partial.p, red_out(h, slot, nb));
   after_reduction(h, slot, nb);
 }
 
 // ---- element-wise
-__global__ __launch_bounds__(256) void k_axpby(int n, double *__restrict__ d, SRef s, SRef a, const double *__restrict__ v,
+__global__ __launch_bounds__(256) void k_axpby(int n, int split, int gap, double *__restrict__ d, SRef s, SRef a, const double *__restrict__ v,
                                                const double *__restrict__ scal, const double *__restrict__ partial, int mode) {
   // mode 0: d = s d + a v ; mode 1: d = a v ; mode 2: d = s d
   __shared__ double sh;
   const double sv = mode == 1 ? 0.0 : sval(scal, partial, s, &sh), av = mode == 2 ? 0.0 : sval(scal, partial, a, &sh);
 #pragma unroll 4
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+  for (int i0 = blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += gridDim.x * 256) {
+    const int i = i0 + (i0 >= split ? gap : 0);
     if (mode == 0) d[i] = sv * d[i] + av * v[i];
     else if (mode == 1) d[i] = av * v[i];
     else d[i] = sv * d[i];
@@ -169,8 +173,9 @@ struct MultiArgs {
   double c[32];
   int k;
 };
-__global__ void k_axpy_multi(int n, double *__restrict__ x, MultiArgs m) {
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+__global__ void k_axpy_multi(int n, int split, int gap, double *__restrict__ x, MultiArgs m) {
+  for (int i0 = blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += gridDim.x * 256) {
+    const int i = i0 + (i0 >= split ? gap : 0);
     double s = x[i];
     for (int j = 0; j < m.k; ++j) s += m.c[j] * m.v[j][i];  // same order as the reference's x.add(h(i), tmp_vectors[i]) loop
     x[i] = s;
@@ -196,9 +201,10 @@ __global__ __launch_bounds__(256) void k_cg_update(int n, double *__restrict__ x
 
 static int ew_blocks(int n) { return std::max(1, std::min(2048, cdiv(n, 512))); }
 
-static void axpby(nsx_handle *h, int n, double *d, SRef s, SRef a, const double *v, int mode, double bytes_per) {
+static void axpby(nsx_handle *h, Span sp, double *d, SRef s, SRef a, const double *v, int mode, double bytes_per) {
+  const int n = sp.n;
   LaunchScope ls(h, "axpby", bytes_per * n);
-  hipLaunchKernelGGL(k_axpby, dim3(ew_blocks(n)), dim3(256), 0, h->stream, n, d, s, a, v, h->scal.p, h->red_partial.p, mode);
+  hipLaunchKernelGGL(k_axpby, dim3(ew_blocks(n)), dim3(256), 0, h->stream, n, sp.split, sp.gap, d, s, a, v, h->scal.p, h->red_partial.p, mode);
 }
 
 void v_copy(nsx_handle *h, int n, double *d, const double *s) {
@@ -207,20 +213,21 @@ void v_copy(nsx_handle *h, int n, double *d, const double *s) {
 void v_zero(nsx_handle *h, int n, double *d) {
   if (n) HIP_CHECK(hipMemsetAsync(d, 0, (size_t)n * sizeof(double), h->stream));
 }
-void v_add(nsx_handle *h, int n, double *d, double a, const double *v) { axpby(h, n, d, SRef{1, -1, -1, 0, 0}, SRef{a, -1, -1, 0, 0}, v, 0, 24); }
-void v_add_dev(nsx_handle *h, int n, double *d, double a, int slot, const double *v) {
+void v_add(nsx_handle *h, Span n, double *d, double a, const double *v) { axpby(h, n, d, SRef{1, -1, -1, 0, 0}, SRef{a, -1, -1, 0, 0}, v, 0, 24); }
+void v_add_dev(nsx_handle *h, Span n, double *d, double a, int slot, const double *v) {
   axpby(h, n, d, SRef{1, -1, -1, 0, 0}, sref(h, a, slot, -1), v, 0, 24);
 }
-void v_sadd(nsx_handle *h, int n, double *d, double s, double a, const double *v) {
+void v_sadd(nsx_handle *h, Span n, double *d, double s, double a, const double *v) {
   axpby(h, n, d, SRef{s, -1, -1, 0, 0}, SRef{a, -1, -1, 0, 0}, v, 0, 24);
 }
-void v_scale(nsx_handle *h, int n, double *d, double a) { axpby(h, n, d, SRef{a, -1, -1, 0, 0}, SRef{0, -1, -1, 0, 0}, nullptr, 2, 16); }
-void v_scale_dev_inv(nsx_handle *h, int n, double *d, int slot) { axpby(h, n, d, sref(h, 1, -1, slot), SRef{0, -1, -1, 0, 0}, nullptr, 2, 16); }
+void v_scale(nsx_handle *h, Span n, double *d, double a) { axpby(h, n, d, SRef{a, -1, -1, 0, 0}, SRef{0, -1, -1, 0, 0}, nullptr, 2, 16); }
+void v_scale_dev_inv(nsx_handle *h, Span n, double *d, int slot) { axpby(h, n, d, sref(h, 1, -1, slot), SRef{0, -1, -1, 0, 0}, nullptr, 2, 16); }
 void v_scale_vec(nsx_handle *h, int n, double *d, const double *f) {
   LaunchScope ls(h, "scale_vec", 24.0 * n);
   hipLaunchKernelGGL(k_scale_vec, dim3(ew_blocks(n)), dim3(256), 0, h->stream, n, d, f);
 }
-void v_axpy_multi(nsx_handle *h, int n, double *x, int k, double *const *vs, const double *coef) {
+void v_axpy_multi(nsx_handle *h, Span sp, double *x, int k, double *const *vs, const double *coef) {
+  const int n = sp.n;
   for (int j0 = 0; j0 < k; j0 += 32) {
     MultiArgs m;
     m.k = std::min(32, k - j0);
@@ -229,7 +236,7 @@ void v_axpy_multi(nsx_handle *h, int n, double *x, int k, double *const *vs, con
       m.c[j] = coef[j0 + j];
     }
     LaunchScope ls(h, "axpy_multi", 8.0 * n * (2 + m.k));
-    hipLaunchKernelGGL(k_axpy_multi, dim3(ew_blocks(n)), dim3(256), 0, h->stream, n, x, m);
+    hipLaunchKernelGGL(k_axpy_multi, dim3(ew_blocks(n)), dim3(256), 0, h->stream, n, sp.split, sp.gap, x, m);
   }
 }
 

@@ -1,5 +1,14 @@
-// nsx_comm.hip — RCCL plumbing: one process per GPU, dot-product all-reduce and ghost-DoF halo exchange over xGMI.
-// Replaces the MPI traffic hidden in Epetra (MPI_Allreduce per dot/norm, Epetra_Import per vmult).
+// nsx_comm.hip — communication of the distributed solve: one process per GPU.
+// Replaces the MPI traffic hidden in Epetra: MPI_Allreduce behind every dot/norm, Epetra_Import
+// (ghost refresh) behind every vmult and behind `solution = solution_owned` (reference NavierStokes3D.cpp:638).
+//
+// Two interchangeable backends behind the same pack/unpack code:
+//   * RCCL over xGMI (nsx_comm_init): ncclAllReduce of the scalar slots on the compute stream; halo = one grouped
+//     ncclSend/ncclRecv per neighbour straight into the ghost region of the vector (ghosts are stored per owner in
+//     rank order, so no unpack kernel is needed).  xGMI is point-to-point: every neighbour pair has its own link.
+//   * host callbacks (nsx_comm_init_callbacks): the same exchange through host buffers and functions supplied by the
+//     caller (MPI in the reference, gloo in the tests) — lets `mpirun` users keep their communicator and lets the
+//     N > 1 path be tested on a single GPU.
 #include <rccl/rccl.h>
 
 #include "nsx_internal.hpp"
@@ -9,6 +18,9 @@ namespace nsx {
 struct Comm {
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1;
+  nsx_allreduce_fn allreduce = nullptr;
+  nsx_exchange_fn exchange = nullptr;
+  void *ctx = nullptr;
 };
 
 #define NCCL_CHECK(expr)                                                                              \
@@ -18,12 +30,70 @@ struct Comm {
   } while (0)
 
 void comm_allreduce_scalars(nsx_handle *h, int slot0, int count) {
-  if (!h->comm || h->comm->world == 1) return;
-  NCCL_CHECK(ncclAllReduce(h->scal.p + slot0, h->scal.p + slot0, count, ncclDouble, ncclSum, h->comm->comm, h->stream));
+  Comm *c = h->comm;
+  if (!c || c->world == 1) return;
+  if (c->comm) {
+    NCCL_CHECK(ncclAllReduce(h->scal.p + slot0, h->scal.p + slot0, count, ncclDouble, ncclSum, c->comm, h->stream));
+  } else {
+    HIP_CHECK(hipMemcpyAsync(h->scal_host + slot0, h->scal.p + slot0, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (c->allreduce(c->ctx, h->scal_host + slot0, count)) NSX_THROW(NSX_ERR_COMM, "allreduce callback failed");
+    HIP_CHECK(hipMemcpyAsync(h->scal.p + slot0, h->scal_host + slot0, (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+  }
 }
 
-void comm_halo_u(nsx_handle *, double *) {}
-void comm_halo_p(nsx_handle *, double *) {}
+template <int NC>
+__global__ void k_pack(int n, const int32_t *__restrict__ idx, const double *__restrict__ x, double *__restrict__ buf) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int i = idx[k];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) buf[(size_t)k * NC + c] = x[(size_t)i * NC + c];
+}
+
+// refresh the ghost part of x (node-major, ncomp values per node) from the owners
+void comm_halo(nsx_handle *h, HaloPlan &p, double *x, int ncomp) {
+  Comm *c = h->comm;
+  const int nn = (int)p.nbr.size();
+  if (nn == 0) return;
+  if (!c || c->world == 1) NSX_THROW(NSX_ERR_COMM, "distributed mesh set but no communicator: call nsx_comm_init* first");
+  const int n_send = p.send_ptr[nn];
+  LaunchScope ls(h, ncomp == 1 ? "halo_p" : "halo_u", 16.0 * (n_send + p.recv_ptr[nn]) * ncomp);
+  if (n_send) {
+    if (ncomp == 1) hipLaunchKernelGGL((k_pack<1>), dim3(cdiv(n_send, 256)), dim3(256), 0, h->stream, n_send, p.send_idx.p, x, p.sendbuf.p);
+    else if (ncomp == 2) hipLaunchKernelGGL((k_pack<2>), dim3(cdiv(n_send, 256)), dim3(256), 0, h->stream, n_send, p.send_idx.p, x, p.sendbuf.p);
+    else hipLaunchKernelGGL((k_pack<3>), dim3(cdiv(n_send, 256)), dim3(256), 0, h->stream, n_send, p.send_idx.p, x, p.sendbuf.p);
+  }
+  double *ghost = x + (size_t)p.n_own * ncomp;
+  if (c->comm) {
+    NCCL_CHECK(ncclGroupStart());
+    for (int k = 0; k < nn; ++k) {
+      const size_t ns = (size_t)(p.send_ptr[k + 1] - p.send_ptr[k]) * ncomp, nr = (size_t)(p.recv_ptr[k + 1] - p.recv_ptr[k]) * ncomp;
+      if (ns) NCCL_CHECK(ncclSend(p.sendbuf.p + (size_t)p.send_ptr[k] * ncomp, ns, ncclDouble, p.nbr[k], c->comm, h->stream));
+      if (nr) NCCL_CHECK(ncclRecv(ghost + (size_t)p.recv_ptr[k] * ncomp, nr, ncclDouble, p.nbr[k], c->comm, h->stream));
+    }
+    NCCL_CHECK(ncclGroupEnd());
+  } else {
+    p.h_send.resize((size_t)n_send * ncomp);
+    p.h_recv.resize((size_t)p.recv_ptr[nn] * ncomp);
+    if (n_send) HIP_CHECK(hipMemcpyAsync(p.h_send.data(), p.sendbuf.p, p.h_send.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    std::vector<const double *> sp(nn);
+    std::vector<double *> rp(nn);
+    std::vector<int> sc(nn), rc(nn), ranks(nn);
+    for (int k = 0; k < nn; ++k) {
+      ranks[k] = p.nbr[k];
+      sp[k] = p.h_send.data() + (size_t)p.send_ptr[k] * ncomp;
+      rp[k] = p.h_recv.data() + (size_t)p.recv_ptr[k] * ncomp;
+      sc[k] = (p.send_ptr[k + 1] - p.send_ptr[k]) * ncomp;
+      rc[k] = (p.recv_ptr[k + 1] - p.recv_ptr[k]) * ncomp;
+    }
+    if (c->exchange(c->ctx, nn, ranks.data(), sp.data(), sc.data(), rp.data(), rc.data())) NSX_THROW(NSX_ERR_COMM, "exchange callback failed");
+    if (!p.h_recv.empty()) HIP_CHECK(hipMemcpyAsync(ghost, p.h_recv.data(), p.h_recv.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+  }
+}
 
 void comm_destroy(nsx_handle *h) {
   if (!h->comm) return;
@@ -62,11 +132,16 @@ int nsx_comm_init(nsx_handle *h, int rank, int world, const uint8_t id[128]) {
   return NSX_OK;
 }
 
-int nsx_set_mesh_distributed(nsx_handle *h, int, int, const int32_t *, const double *, int, int, int, const int32_t *, const int32_t *) {
-  if (!h) return NSX_ERR_ARG;
-  h->err = "nsx_set_mesh_distributed: the distributed (owned + ghost) mesh path is not implemented in this round; "
-           "multi-GPU runs use one replica per rank";
-  return NSX_ERR_UNSUPPORTED;
+int nsx_comm_init_callbacks(nsx_handle *h, int rank, int world, nsx_allreduce_fn allreduce, nsx_exchange_fn exchange, void *ctx) {
+  if (!h || world < 1 || rank < 0 || rank >= world || !allreduce || !exchange) return NSX_ERR_ARG;
+  nsx::comm_destroy(h);
+  h->comm = new nsx::Comm;
+  h->comm->rank = rank;
+  h->comm->world = world;
+  h->comm->allreduce = allreduce;
+  h->comm->exchange = exchange;
+  h->comm->ctx = ctx;
+  return NSX_OK;
 }
 
 }  // extern "C"

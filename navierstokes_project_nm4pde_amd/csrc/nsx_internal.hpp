@@ -113,6 +113,17 @@ struct IluSchedule {
   DevBuf<double> pk_dinv;       // [n_rows] inverse pivots
 };
 
+// Ghost exchange plan of one scalar space (the Epetra_Import of every vmult): neighbours in ascending rank order,
+// what to pack for each, and where each neighbour's values land in the ghost part of a vector.
+struct HaloPlan {
+  std::vector<int> nbr;
+  std::vector<int32_t> send_ptr, recv_ptr;  // [n_nbr+1], node units
+  DevBuf<int32_t> send_idx;                 // local (owned) node ids to pack
+  DevBuf<double> sendbuf;
+  std::vector<double> h_send, h_recv;       // host staging for the callback backend
+  int n_own = 0;                            // ghosts start at node n_own
+};
+
 struct ProfEntry {
   int64_t launches = 0;
   double bytes = 0;  // algorithmic bytes of one launch (last seen)
@@ -134,6 +145,13 @@ struct nsx_handle {
   int dim = 0, n_q = 0, np2 = 0, np1 = 0, dpc = 0;
   int n_cells = 0, N2 = 0, NP = 0, n_u = 0, n_p = 0;  // local sizes (rows owned by this handle)
   int N2_loc = 0, NP_loc = 0;                          // owned + ghost (== N2, NP on one GPU)
+  // vector layout [u_owned (n_u) | u_ghost (g_u) | p_owned (n_p) | p_ghost (g_p)]; off_p = n_u + g_u
+  int n_cells1 = 0;                                    // layer-1 cells (touch an owned node): the per-step cell loop
+  int g_u = 0, g_p = 0, off_p = 0, len_blk = 0, len_u = 0, len_p = 0;
+  bool dist = false;
+  int rank = 0, world = 1, goff_u = 0, goff_p = 0, n_u_glob = 0, n_p_glob = 0;  // global numbering of this rank's range
+  std::vector<int32_t> ghost_u, ghost_p;               // global ids of the ghost nodes (sorted)
+  nsx::HaloPlan haloU, haloP;
   bool have_tables = false, have_mesh = false, assembled = false, prec_ready = false;
   std::vector<double> N2_h, dN2_h, N1_h, w_h;
   nsx::DevBuf<double> tab_N2, tab_dN2, tab_N1, tab_w, tab_N2T, tab_dN2T;  // T: [a][q] / [b][q][k]
@@ -219,19 +237,28 @@ void ilu_solve(nsx_handle *h, const DevCsr &g, const IluSchedule &s, const doubl
 void extract_diag(nsx_handle *h, const DevCsr &g, const double *vals, double *d);           // scalar diag
 void abs_rowsum(nsx_handle *h, const DevCsr &g, const double *vals, double *d);
 
+// Index span of a BLAS-1 operation: n owned entries; entries at i >= split sit `gap` further (the ghost velocity block
+// between the owned velocity and the owned pressure part of a distributed block vector).  Plain vectors: Span(n).
+struct Span {
+  int n, split, gap;
+  Span(int n_) : n(n_), split(n_), gap(0) {}
+  Span(int n_, int split_, int gap_) : n(n_), split(split_), gap(gap_) {}
+};
+inline Span blk_span(const nsx_handle *h) { return Span(h->n_u + h->n_p, h->n_u, h->g_u); }
+
 // BLAS-1 (nsx_blas.hip): scalars live in h->scal[slot]
-void v_copy(nsx_handle *h, int n, double *d, const double *s);
+void v_copy(nsx_handle *h, int n, double *d, const double *s);  // raw copy of n contiguous entries
 void v_zero(nsx_handle *h, int n, double *d);
-void v_add(nsx_handle *h, int n, double *d, double a, const double *v);                     // d += a v
-void v_add_dev(nsx_handle *h, int n, double *d, double a, int slot, const double *v);       // d += a*scal[slot]*v
-void v_sadd(nsx_handle *h, int n, double *d, double s, double a, const double *v);          // d = s d + a v
-void v_scale(nsx_handle *h, int n, double *d, double a);
-void v_scale_dev_inv(nsx_handle *h, int n, double *d, int slot);                            // d *= 1/scal[slot]
+void v_add(nsx_handle *h, Span n, double *d, double a, const double *v);                     // d += a v
+void v_add_dev(nsx_handle *h, Span n, double *d, double a, int slot, const double *v);       // d += a*scal[slot]*v
+void v_sadd(nsx_handle *h, Span n, double *d, double s, double a, const double *v);          // d = s d + a v
+void v_scale(nsx_handle *h, Span n, double *d, double a);
+void v_scale_dev_inv(nsx_handle *h, Span n, double *d, int slot);                            // d *= 1/scal[slot]
 void v_scale_vec(nsx_handle *h, int n, double *d, const double *f);
-void v_dot(nsx_handle *h, int n, const double *a, const double *b, int slot);               // scal[slot] = a.b
-void v_add_and_dot(nsx_handle *h, int n, double *d, double a, int aslot, const double *v, const double *w, int slot);
+void v_dot(nsx_handle *h, Span n, const double *a, const double *b, int slot);               // scal[slot] = a.b
+void v_add_and_dot(nsx_handle *h, Span n, double *d, double a, int aslot, const double *v, const double *w, int slot);
                                                                                             // d += a*scal[aslot]*v ; scal[slot] = d.w
-void v_axpy_multi(nsx_handle *h, int n, double *x, int k, double *const *vs, const double *coef_host);
+void v_axpy_multi(nsx_handle *h, Span n, double *x, int k, double *const *vs, const double *coef_host);
 void finalize_slots(nsx_handle *h, int slot0, int count);
 double read_scalar(nsx_handle *h, int slot);
 void read_scalars(nsx_handle *h, int slot0, int count, double *out);
@@ -246,8 +273,9 @@ void solve_time_step(nsx_handle *h, int type, double tol, double inner_rtol, int
 
 // comm (nsx_comm.hip)
 void comm_allreduce_scalars(nsx_handle *h, int slot0, int count);
-void comm_halo_u(nsx_handle *h, double *x);
-void comm_halo_p(nsx_handle *h, double *x);
+void comm_halo(nsx_handle *h, HaloPlan &plan, double *x, int ncomp);
+inline void comm_halo_u(nsx_handle *h, const double *x) { if (h->dist) comm_halo(h, h->haloU, const_cast<double *>(x), h->dim); }
+inline void comm_halo_p(nsx_handle *h, const double *x) { if (h->dist) comm_halo(h, h->haloP, const_cast<double *>(x), 1); }
 void comm_destroy(nsx_handle *h);
 
 }  // namespace nsx

@@ -36,7 +36,12 @@ static void build_gather(nsx_handle *h, const Csr &g, int n_cells, int per_r, co
   for (int c = 0; c < n_cells; ++c)
     for (int a = 0; a < per_r; ++a)
       for (int b = 0; b < per_c; ++b) {
-        const int32_t e = find_in_row(g, cell_r[(size_t)c * per_r + a], cell_c[(size_t)c * per_c + b]);
+        const int32_t row = cell_r[(size_t)c * per_r + a];
+        if (row >= g.n_rows) {  // ghost row: assembled by its owner
+          epos[((size_t)c * per_r + a) * per_c + b] = -1;
+          continue;
+        }
+        const int32_t e = find_in_row(g, row, cell_c[(size_t)c * per_c + b]);
         if (e < 0) NSX_THROW(NSX_ERR_ARG, "internal: cell pair not in graph");
         epos[((size_t)c * per_r + a) * per_c + b] = e;
         ptr[e + 1]++;
@@ -48,6 +53,7 @@ static void build_gather(nsx_handle *h, const Csr &g, int n_cells, int per_r, co
     for (int a = 0; a < per_r; ++a)
       for (int b = 0; b < per_c; ++b) {
         const int32_t e = epos[((size_t)c * per_r + a) * per_c + b];
+        if (e < 0) continue;
         const int64_t plane = plane_rc_swapped ? ((int64_t)b * per_r + a) : ((int64_t)a * per_c + b);
         const int64_t off = plane * plane_stride * n_cells + c;
         if (off > INT32_MAX) NSX_THROW(NSX_ERR_UNSUPPORTED, "mesh too large for int32 gather offsets");
@@ -206,19 +212,28 @@ void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> 
 }
 
 void build_schur_graph(nsx_handle *h) {
-  // structural product of block(1,0) [P1 x P2] and block(0,1) [P2 x P1]
-  const Csr &B = h->gB.host, &G = h->gG.host;
+  // structural product block(1,0) * block(0,1); block(0,1) has the transposed pattern of block(1,0), and block(1,0)
+  // is stored for every local (owned + ghost) pressure row, so the product is formed from B and B^T alone
+  const Csr &B = h->gB.host;
+  std::vector<int32_t> tp((size_t)h->N2_loc + 1, 0), tr(B.nnz());
+  for (int64_t k = 0; k < B.nnz(); ++k) tp[B.colind[k] + 1]++;
+  for (int i = 0; i < h->N2_loc; ++i) tp[i + 1] += tp[i];
+  {
+    std::vector<int32_t> fill(tp.begin(), tp.end() - 1);
+    for (int j = 0; j < B.n_rows; ++j)
+      for (int k = B.rowptr[j]; k < B.rowptr[j + 1]; ++k) tr[fill[B.colind[k]]++] = j;
+  }
   Csr S;
-  S.n_rows = S.n_cols = h->NP;
+  S.n_rows = h->NP;
+  S.n_cols = h->NP_loc;
   S.rowptr.assign((size_t)h->NP + 1, 0);
   std::vector<int32_t> mark(h->NP_loc, -1), cols;
   for (int i = 0; i < h->NP; ++i) {
     cols.clear();
     for (int kb = B.rowptr[i]; kb < B.rowptr[i + 1]; ++kb) {
       const int k = B.colind[kb];
-      if (k >= G.n_rows) continue;  // ghost P2 node: its G row lives on another rank
-      for (int kg = G.rowptr[k]; kg < G.rowptr[k + 1]; ++kg) {
-        const int j = G.colind[kg];
+      for (int q = tp[k]; q < tp[k + 1]; ++q) {
+        const int j = tr[q];
         if (mark[j] != i) {
           mark[j] = i;
           cols.push_back(j);
@@ -355,21 +370,22 @@ int nsx_set_tables(nsx_handle *h, int n_q, int n_p2, int n_p1, const double *N2,
   NSX_CATCH(h)
 }
 
-int nsx_set_mesh(nsx_handle *h, int n_cells, int dpc, const int32_t *cell_dofs, const double *cell_coords, int n_u, int n_p) {
-  NSX_TRY(h)
-  if (!h->have_tables) NSX_THROW(NSX_ERR_ARG, "nsx_set_tables must be called before nsx_set_mesh");
-  if (!cell_dofs || !cell_coords || n_cells < 1) NSX_THROW(NSX_ERR_ARG, "empty mesh");
-  HIP_CHECK(hipSetDevice(h->prm.device));
-  const int dim = h->dim, nv = dim + 1, nl = dim == 2 ? 3 : 6, np2 = h->np2, np1 = h->np1;
-  if (dpc != nv * (dim + 1) + nl * dim) NSX_THROW(NSX_ERR_ARG, "dofs_per_cell %d does not match FESystem(P2^%d,P1)", dpc, dim);
-  if (n_u % dim) NSX_THROW(NSX_ERR_ARG, "n_u not a multiple of dim");
-  h->dpc = dpc;
-  h->n_cells = n_cells;
-  h->n_u = n_u;
-  h->n_p = n_p;
-  h->N2 = h->N2_loc = n_u / dim;
-  h->NP = h->NP_loc = n_p;
-  // scalar connectivity from the FESystem dof table
+}  // extern "C"
+
+namespace {
+using namespace nsx;
+
+void truncate_rows(nsx::Csr &g, int n_rows) {
+  if (g.n_rows <= n_rows) return;
+  g.colind.resize(g.rowptr[n_rows]);
+  g.rowptr.resize((size_t)n_rows + 1);
+  g.n_rows = n_rows;
+}
+
+// scalar connectivity (local node ids) from the FESystem dof table; `loc2`/`loc1` map a global node to its local id
+template <class M2, class M1>
+void connectivity(nsx_handle *h, int n_cells, int dpc, const int32_t *cell_dofs, int n_u_glob, int n_p_glob, M2 loc2, M1 loc1) {
+  const int dim = h->dim, nv = dim + 1, np2 = h->np2, np1 = h->np1;
   h->cell_n2_h.resize((size_t)n_cells * np2);
   h->cell_n1_h.resize((size_t)n_cells * np1);
   for (int c = 0; c < n_cells; ++c) {
@@ -377,29 +393,51 @@ int nsx_set_mesh(nsx_handle *h, int n_cells, int dpc, const int32_t *cell_dofs, 
     for (int a = 0; a < np2; ++a) {
       const int base = a < nv ? (dim + 1) * a : nv * (dim + 1) + dim * (a - nv);
       const int32_t d0 = cd[base];
-      if (d0 < 0 || d0 >= n_u || d0 % dim) NSX_THROW(NSX_ERR_ARG, "cell %d: velocity dof %d breaks the dim*node+c numbering contract", c, d0);
+      if (d0 < 0 || d0 >= n_u_glob || d0 % dim) NSX_THROW(NSX_ERR_ARG, "cell %d: velocity dof %d breaks the dim*node+c numbering contract", c, d0);
       for (int k = 1; k < dim; ++k)
         if (cd[base + k] != d0 + k) NSX_THROW(NSX_ERR_ARG, "cell %d: velocity components of one node are not consecutive", c);
-      h->cell_n2_h[(size_t)c * np2 + a] = d0 / dim;
+      const int32_t l = loc2(d0 / dim);
+      if (l < 0) NSX_THROW(NSX_ERR_ARG, "cell %d: P2 node %d is neither owned nor a known ghost", c, d0 / dim);
+      h->cell_n2_h[(size_t)c * np2 + a] = l;
     }
     for (int v = 0; v < nv; ++v) {
-      const int32_t d = cd[(dim + 1) * v + dim] - n_u;
-      if (d < 0 || d >= n_p) NSX_THROW(NSX_ERR_ARG, "cell %d: pressure dof out of range", c);
-      h->cell_n1_h[(size_t)c * np1 + v] = d;
+      const int32_t d = cd[(dim + 1) * v + dim] - n_u_glob;
+      if (d < 0 || d >= n_p_glob) NSX_THROW(NSX_ERR_ARG, "cell %d: pressure dof out of range", c);
+      const int32_t l = loc1(d);
+      if (l < 0) NSX_THROW(NSX_ERR_ARG, "cell %d: P1 node %d is neither owned nor a known ghost", c, d);
+      h->cell_n1_h[(size_t)c * np1 + v] = l;
     }
   }
-  // graphs (reference NavierStokes3D.cpp:109-124, pressure mass :127-142)
+}
+
+// everything that follows the connectivity: graphs, geometry, gather maps, buffers, Schur pattern, ILU schedules
+void setup_mesh(nsx_handle *h, int n_cells, int n_cells1, const double *cell_coords) {
+  using namespace nsx;
+  const int dim = h->dim, nv = dim + 1, np2 = h->np2, np1 = h->np1;
+  h->n_cells = n_cells;
+  h->n_cells1 = n_cells1;
+  h->n_u = dim * h->N2;
+  h->n_p = h->NP;
+  h->g_u = dim * (h->N2_loc - h->N2);
+  h->g_p = h->NP_loc - h->NP;
+  h->off_p = h->n_u + h->g_u;
+  h->len_u = h->n_u + h->g_u;
+  h->len_p = h->n_p + h->g_p;
+  h->len_blk = h->len_u + h->len_p;
+  // graphs (reference NavierStokes3D.cpp:109-124, pressure mass :127-142): owned rows, local (owned + ghost) columns
   const int32_t *c2 = h->cell_n2_h.data(), *c1 = h->cell_n1_h.data();
-  h->gA.host = build_graph(n_cells, np2, c2, h->N2, np2, c2, h->N2);
-  h->gG.host = build_graph(n_cells, np2, c2, h->N2, np1, c1, h->NP);
-  h->gB.host = build_graph(n_cells, np1, c1, h->NP, np2, c2, h->N2);
-  h->gPM.host = build_graph(n_cells, np1, c1, h->NP, np1, c1, h->NP);
+  h->gA.host = build_graph(n_cells, np2, c2, h->N2_loc, np2, c2, h->N2_loc);
+  truncate_rows(h->gA.host, h->N2);
+  h->gG.host = build_graph(n_cells, np2, c2, h->N2_loc, np1, c1, h->NP_loc);
+  truncate_rows(h->gG.host, h->N2);
+  h->gB.host = build_graph(n_cells, np1, c1, h->NP_loc, np2, c2, h->N2_loc);  // all local rows: the Schur product needs ghost rows
+  h->gPM.host = build_graph(n_cells, np1, c1, h->NP_loc, np1, c1, h->NP_loc);
+  truncate_rows(h->gPM.host, h->NP);
   upload_csr(h, h->gA, true);
   upload_csr(h, h->gG, false);
   upload_csr(h, h->gB, false);
   upload_csr(h, h->gPM, true);
-  // SoA cell tables + geometry
-  {
+  {  // SoA cell tables + geometry
     std::vector<int32_t> t2((size_t)n_cells * np2), t1((size_t)n_cells * np1);
     for (int c = 0; c < n_cells; ++c) {
       for (int a = 0; a < np2; ++a) t2[(size_t)a * n_cells + c] = c2[(size_t)c * np2 + a];
@@ -457,18 +495,144 @@ int nsx_set_mesh(nsx_handle *h, int n_cells, int dpc, const int32_t *cell_dofs, 
   h->vG.alloc(h->gG.nnz() * dim);
   h->vB.alloc(h->gB.nnz() * dim);
   h->vPM.alloc(h->gPM.nnz());
-  const size_t n = (size_t)n_u + n_p;
   for (auto *v : {&h->sol, &h->sol_owned, &h->prev_sol, &h->rhs}) {
-    v->alloc(n);
+    v->alloc(h->len_blk);
     v->zero(h->stream);
   }
-  for (auto *v : {&h->diag_D, &h->diag_D_inv, &h->neg_diag_D_inv, &h->lump_M, &h->schur_w, &h->dirmask}) v->alloc(n_u);
+  for (auto *v : {&h->diag_D, &h->diag_D_inv, &h->neg_diag_D_inv, &h->lump_M, &h->schur_w, &h->dirmask}) {
+    v->alloc(h->len_u);
+    v->zero(h->stream);
+  }
   build_schur_graph(h);
   default_ranks(h);
   refresh_rank_products(h);
   HIP_CHECK(hipStreamSynchronize(h->stream));
   h->have_mesh = true;
   h->assembled = false;
+  h->bc_cache.clear();
+}
+
+void halo_plan(nsx_handle *h, nsx::HaloPlan &p, int n_own, int goff, const std::vector<int32_t> &ghosts, const int32_t *gpu_ptr,
+               int n_nbr, const int32_t *nbr, const int32_t *send_ptr, const int32_t *send_nodes, int ncomp) {
+  p.n_own = n_own;
+  p.nbr.assign(nbr, nbr + n_nbr);
+  p.send_ptr.assign(send_ptr, send_ptr + n_nbr + 1);
+  std::vector<int32_t> idx(send_ptr[n_nbr]);
+  for (int k = 0; k < send_ptr[n_nbr]; ++k) {
+    const int32_t l = send_nodes[k] - goff;
+    if (l < 0 || l >= n_own) NSX_THROW(NSX_ERR_ARG, "halo plan: node %d to send is not owned by this rank", send_nodes[k]);
+    idx[k] = l;
+  }
+  p.send_idx.upload(idx, h->stream);
+  p.sendbuf.alloc((size_t)std::max<int32_t>(1, send_ptr[n_nbr]) * ncomp);
+  // ghosts are sorted by global id, i.e. grouped by owner in rank order
+  p.recv_ptr.assign((size_t)n_nbr + 1, 0);
+  size_t g = 0;
+  for (int k = 0; k < n_nbr; ++k) {
+    const int r = nbr[k];
+    if (k > 0 && nbr[k] <= nbr[k - 1]) NSX_THROW(NSX_ERR_ARG, "halo plan: neighbours must be ascending");
+    size_t g1 = g;
+    while (g1 < ghosts.size() && ghosts[g1] < gpu_ptr[r + 1]) {
+      if (ghosts[g1] < gpu_ptr[r]) NSX_THROW(NSX_ERR_ARG, "halo plan: ghost node %d belongs to a rank that is not a neighbour", ghosts[g1]);
+      ++g1;
+    }
+    p.recv_ptr[k + 1] = (int32_t)g1;
+    g = g1;
+  }
+  if (g != ghosts.size()) NSX_THROW(NSX_ERR_ARG, "halo plan: %zu ghost nodes have no neighbour to come from", ghosts.size() - g);
+}
+
+}  // namespace
+
+extern "C" {
+
+int nsx_set_mesh(nsx_handle *h, int n_cells, int dpc, const int32_t *cell_dofs, const double *cell_coords, int n_u, int n_p) {
+  NSX_TRY(h)
+  if (!h->have_tables) NSX_THROW(NSX_ERR_ARG, "nsx_set_tables must be called before nsx_set_mesh");
+  if (!cell_dofs || !cell_coords || n_cells < 1) NSX_THROW(NSX_ERR_ARG, "empty mesh");
+  HIP_CHECK(hipSetDevice(h->prm.device));
+  const int dim = h->dim, nv = dim + 1, nl = dim == 2 ? 3 : 6;
+  if (dpc != nv * (dim + 1) + nl * dim) NSX_THROW(NSX_ERR_ARG, "dofs_per_cell %d does not match FESystem(P2^%d,P1)", dpc, dim);
+  if (n_u % dim) NSX_THROW(NSX_ERR_ARG, "n_u not a multiple of dim");
+  h->dpc = dpc;
+  h->dist = false;
+  h->rank = 0;
+  h->world = 1;
+  h->goff_u = h->goff_p = 0;
+  h->n_u_glob = n_u;
+  h->n_p_glob = n_p;
+  h->N2 = h->N2_loc = n_u / dim;
+  h->NP = h->NP_loc = n_p;
+  h->ghost_u.clear();
+  h->ghost_p.clear();
+  connectivity(h, n_cells, dpc, cell_dofs, n_u, n_p, [](int32_t g) { return g; }, [](int32_t g) { return g; });
+  setup_mesh(h, n_cells, n_cells, cell_coords);
+  NSX_CATCH(h)
+}
+
+int nsx_set_mesh_distributed(nsx_handle *h, int n_cells, int n_cells1, int dpc, const int32_t *cell_dofs, const double *cell_coords,
+                             int n_u_glob, int n_p_glob, int world, int rank, const int32_t *gpu_u_ptr, const int32_t *gpu_p_ptr,
+                             int n_nbr, const int32_t *nbr, const int32_t *send_u_ptr, const int32_t *send_u_nodes,
+                             const int32_t *send_p_ptr, const int32_t *send_p_nodes) {
+  NSX_TRY(h)
+  if (!h->have_tables) NSX_THROW(NSX_ERR_ARG, "nsx_set_tables must be called before nsx_set_mesh_distributed");
+  if (!cell_dofs || !cell_coords || n_cells < 1 || n_cells1 < 1 || n_cells1 > n_cells) NSX_THROW(NSX_ERR_ARG, "empty mesh");
+  if (world < 1 || rank < 0 || rank >= world || !gpu_u_ptr || !gpu_p_ptr) NSX_THROW(NSX_ERR_ARG, "bad rank / ownership table");
+  if (n_nbr < 0 || (n_nbr > 0 && (!nbr || !send_u_ptr || !send_p_ptr))) NSX_THROW(NSX_ERR_ARG, "bad halo plan");
+  HIP_CHECK(hipSetDevice(h->prm.device));
+  const int dim = h->dim, nv = dim + 1, nl = dim == 2 ? 3 : 6, np2 = h->np2;
+  if (dpc != nv * (dim + 1) + nl * dim) NSX_THROW(NSX_ERR_ARG, "dofs_per_cell %d does not match FESystem(P2^%d,P1)", dpc, dim);
+  if (gpu_u_ptr[0] != 0 || gpu_p_ptr[0] != 0 || gpu_u_ptr[world] * dim != n_u_glob || gpu_p_ptr[world] != n_p_glob)
+    NSX_THROW(NSX_ERR_ARG, "ownership ranges must cover all global nodes");
+  h->dpc = dpc;
+  h->dist = world > 1;
+  h->rank = rank;
+  h->world = world;
+  h->goff_u = gpu_u_ptr[rank];
+  h->goff_p = gpu_p_ptr[rank];
+  h->n_u_glob = n_u_glob;
+  h->n_p_glob = n_p_glob;
+  h->N2 = gpu_u_ptr[rank + 1] - gpu_u_ptr[rank];
+  h->NP = gpu_p_ptr[rank + 1] - gpu_p_ptr[rank];
+  // ghost sets = nodes of the local cells that this rank does not own, sorted by global id
+  {
+    std::vector<int32_t> g2, g1;
+    for (int c = 0; c < n_cells; ++c) {
+      const int32_t *cd = cell_dofs + (size_t)c * dpc;
+      for (int a = 0; a < np2; ++a) {
+        const int32_t n = cd[a < nv ? (dim + 1) * a : nv * (dim + 1) + dim * (a - nv)] / dim;
+        if (n < gpu_u_ptr[rank] || n >= gpu_u_ptr[rank + 1]) g2.push_back(n);
+      }
+      for (int v = 0; v < nv; ++v) {
+        const int32_t n = cd[(dim + 1) * v + dim] - n_u_glob;
+        if (n < gpu_p_ptr[rank] || n >= gpu_p_ptr[rank + 1]) g1.push_back(n);
+      }
+    }
+    std::sort(g2.begin(), g2.end());
+    g2.erase(std::unique(g2.begin(), g2.end()), g2.end());
+    std::sort(g1.begin(), g1.end());
+    g1.erase(std::unique(g1.begin(), g1.end()), g1.end());
+    h->ghost_u = std::move(g2);
+    h->ghost_p = std::move(g1);
+  }
+  h->N2_loc = h->N2 + (int)h->ghost_u.size();
+  h->NP_loc = h->NP + (int)h->ghost_p.size();
+  auto loc = [](int32_t g, int32_t off, int32_t n_own, const std::vector<int32_t> &ghosts) -> int32_t {
+    if (g >= off && g < off + n_own) return g - off;
+    auto it = std::lower_bound(ghosts.begin(), ghosts.end(), g);
+    return (it != ghosts.end() && *it == g) ? n_own + (int32_t)(it - ghosts.begin()) : -1;
+  };
+  connectivity(h, n_cells, dpc, cell_dofs, n_u_glob, n_p_glob,
+               [&](int32_t g) { return loc(g, h->goff_u, h->N2, h->ghost_u); }, [&](int32_t g) { return loc(g, h->goff_p, h->NP, h->ghost_p); });
+  // layer-1 cells must be exactly those touching an owned P2 node (all of them first)
+  for (int c = 0; c < n_cells; ++c) {
+    bool own = false;
+    for (int a = 0; a < np2 && !own; ++a) own = h->cell_n2_h[(size_t)c * np2 + a] < h->N2;
+    if (own != (c < n_cells1)) NSX_THROW(NSX_ERR_ARG, "cell %d: layer-1 cells (touching an owned node) must come first", c);
+  }
+  halo_plan(h, h->haloU, h->N2, h->goff_u, h->ghost_u, gpu_u_ptr, n_nbr, nbr, send_u_ptr, send_u_nodes, dim);
+  halo_plan(h, h->haloP, h->NP, h->goff_p, h->ghost_p, gpu_p_ptr, n_nbr, nbr, send_p_ptr, send_p_nodes, 1);
+  setup_mesh(h, n_cells, n_cells1, cell_coords);
   NSX_CATCH(h)
 }
 
@@ -476,13 +640,17 @@ int nsx_set_ranks(nsx_handle *h, int n_ranks, const int32_t *u_ptr, const int32_
   NSX_TRY(h)
   if (!h->have_mesh) NSX_THROW(NSX_ERR_ARG, "nsx_set_mesh first");
   if (n_ranks < 1 || !u_ptr || !p_ptr) NSX_THROW(NSX_ERR_ARG, "bad rank table");
-  if (u_ptr[0] != 0 || p_ptr[0] != 0 || u_ptr[n_ranks] != h->N2 || p_ptr[n_ranks] != h->NP)
-    NSX_THROW(NSX_ERR_ARG, "rank ranges must cover [0,N2) and [0,NP)");
+  if (u_ptr[0] != h->goff_u || p_ptr[0] != h->goff_p || u_ptr[n_ranks] != h->goff_u + h->N2 || p_ptr[n_ranks] != h->goff_p + h->NP)
+    NSX_THROW(NSX_ERR_ARG, "rank ranges must cover exactly the nodes owned by this handle");
   for (int r = 0; r < n_ranks; ++r)
     if (u_ptr[r + 1] < u_ptr[r] || p_ptr[r + 1] < p_ptr[r]) NSX_THROW(NSX_ERR_ARG, "rank ranges must be ascending");
   HIP_CHECK(hipSetDevice(h->prm.device));
-  h->rank_u_h.assign(u_ptr, u_ptr + n_ranks + 1);
-  h->rank_p_h.assign(p_ptr, p_ptr + n_ranks + 1);
+  h->rank_u_h.resize((size_t)n_ranks + 1);
+  h->rank_p_h.resize((size_t)n_ranks + 1);
+  for (int r = 0; r <= n_ranks; ++r) {
+    h->rank_u_h[r] = u_ptr[r] - h->goff_u;
+    h->rank_p_h[r] = p_ptr[r] - h->goff_p;
+  }
   refresh_rank_products(h);
   NSX_CATCH(h)
 }
@@ -490,25 +658,44 @@ int nsx_set_ranks(nsx_handle *h, int n_ranks, const int32_t *u_ptr, const int32_
 int nsx_set_schur_blocks(nsx_handle *h, int n_blocks, const int32_t *p_ptr) {
   NSX_TRY(h)
   if (!h->have_mesh) NSX_THROW(NSX_ERR_ARG, "nsx_set_mesh first");
-  if (n_blocks < 1 || !p_ptr || p_ptr[0] != 0 || p_ptr[n_blocks] != h->NP) NSX_THROW(NSX_ERR_ARG, "bad Schur block table");
+  if (n_blocks < 1 || !p_ptr || p_ptr[0] != h->goff_p || p_ptr[n_blocks] != h->goff_p + h->NP) NSX_THROW(NSX_ERR_ARG, "bad Schur block table");
   HIP_CHECK(hipSetDevice(h->prm.device));
-  h->sblk_h.assign(p_ptr, p_ptr + n_blocks + 1);
+  h->sblk_h.resize((size_t)n_blocks + 1);
+  for (int r = 0; r <= n_blocks; ++r) h->sblk_h[r] = p_ptr[r] - h->goff_p;
   refresh_rank_products(h);
   NSX_CATCH(h)
 }
 
-// ---- state
+// ---- state: host vectors use the GLOBAL numbering [n_u_glob | n_p_glob]; a rank reads owned + ghost entries and writes owned ones
 static int vec_io(nsx_handle *h, nsx::DevBuf<double> &v, double *out, const double *in) {
   NSX_TRY(h)
   if (!h->have_mesh) NSX_THROW(NSX_ERR_ARG, "nsx_set_mesh first");
   HIP_CHECK(hipSetDevice(h->prm.device));
-  const size_t n = (size_t)h->n_u + h->n_p;
-  if (in) {
-    HIP_CHECK(hipMemcpyAsync(v.p, in, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  const int dim = h->dim;
+  if (!h->dist) {
+    const size_t n = (size_t)h->n_u + h->n_p;
+    if (in) {
+      HIP_CHECK(hipMemcpyAsync(v.p, in, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+      HIP_CHECK(hipStreamSynchronize(h->stream));
+    } else {
+      if (!out) NSX_THROW(NSX_ERR_ARG, "null output");
+      v.download(out, n, h->stream);
+    }
+  } else if (in) {
+    std::vector<double> loc(h->len_blk);
+    for (int i = 0; i < h->n_u; ++i) loc[i] = in[(size_t)dim * h->goff_u + i];
+    for (size_t g = 0; g < h->ghost_u.size(); ++g)
+      for (int c = 0; c < dim; ++c) loc[h->n_u + g * dim + c] = in[(size_t)dim * h->ghost_u[g] + c];
+    for (int i = 0; i < h->n_p; ++i) loc[h->off_p + i] = in[(size_t)h->n_u_glob + h->goff_p + i];
+    for (size_t g = 0; g < h->ghost_p.size(); ++g) loc[h->off_p + h->n_p + g] = in[(size_t)h->n_u_glob + h->ghost_p[g]];
+    HIP_CHECK(hipMemcpyAsync(v.p, loc.data(), loc.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_CHECK(hipStreamSynchronize(h->stream));
   } else {
     if (!out) NSX_THROW(NSX_ERR_ARG, "null output");
-    v.download(out, n, h->stream);
+    std::vector<double> loc(h->len_blk);
+    v.download(loc.data(), loc.size(), h->stream);
+    for (int i = 0; i < h->n_u; ++i) out[(size_t)dim * h->goff_u + i] = loc[i];
+    for (int i = 0; i < h->n_p; ++i) out[(size_t)h->n_u_glob + h->goff_p + i] = loc[h->off_p + i];
   }
   NSX_CATCH(h)
 }
@@ -558,6 +745,7 @@ int nsx_schur_get(nsx_handle *h, int32_t *rowptr, int32_t *colind, double *value
 int nsx_export_block(nsx_handle *h, int which, int block, int n_rows, const int32_t *rowptr, const int32_t *colind, double *values) {
   NSX_TRY(h)
   if (!h->assembled) NSX_THROW(NSX_ERR_ARG, "nothing assembled yet");
+  if (h->dist) NSX_THROW(NSX_ERR_UNSUPPORTED, "nsx_export_block works on a single-process handle only");
   if (!rowptr || !colind || !values) NSX_THROW(NSX_ERR_ARG, "null graph");
   HIP_CHECK(hipSetDevice(h->prm.device));
   const int dim = h->dim;

@@ -64,13 +64,13 @@ constexpr int N_TMP = 30;  // SolverGMRES::AdditionalData::max_n_tmp_vectors
 enum { S_H = 8 /* 8..8+N_TMP */, S_NRM = 40, S_H2 = 41 /* re-orthogonalisation coefficients 41..41+N_TMP */, S_GH = 2, S_DH = 3, S_RES = 4, S_GH2 = 5, S_T = 6 };
 
 // SolverGMRES<VectorType>::solve (left preconditioning, default residual).
-static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b, const Op &P, int n, double tol, int maxiter) {
+static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b, const Op &P, Span n, int len, double tol, int maxiter) {
   SolveResult res{1, 0, 0.0};
   std::vector<std::unique_ptr<Tmp>> tmp(N_TMP);
   auto vec = [&](int i) -> double * {
     if (!tmp[i]) {
-      tmp[i] = std::make_unique<Tmp>(h, n);
-      v_zero(h, n, tmp[i]->p());  // a freshly created Epetra vector is zero
+      tmp[i] = std::make_unique<Tmp>(h, len);
+      v_zero(h, len, tmp[i]->p());  // a freshly created Epetra vector is zero
     }
     return tmp[i]->p();
   };
@@ -152,9 +152,9 @@ static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b,
 }
 
 // SolverCG<VectorType>::solve with a preconditioner.
-static SolveResult cg(nsx_handle *h, const Op &A, double *x, const double *b, const Op &P, int n, double tol, int maxiter) {
+static SolveResult cg(nsx_handle *h, const Op &A, double *x, const double *b, const Op &P, Span n, int len, double tol, int maxiter) {
   SolveResult res{1, 0, 0.0};
-  Tmp g(h, n), d(h, n), hv(h, n);
+  Tmp g(h, len), d(h, len), hv(h, len);
   int it = 0;
   // g = A x - b.  deal.II short-cuts to g = -b when x.all_zero(); A*0 - b gives the identical vector, so no device-side test is needed.
   A(g.p(), x);
@@ -165,7 +165,7 @@ static SolveResult cg(nsx_handle *h, const Op &A, double *x, const double *b, co
   int conv = sc_check(0, r, tol, maxiter);
   if (conv == 0) {
     P(hv.p(), g.p());
-    v_copy(h, n, d.p(), hv.p());
+    v_copy(h, n.n, d.p(), hv.p());
     v_scale(h, n, d.p(), -1.);
     int gh = S_GH, gh_new = S_GH2;  // ping-pong slots for (g.h) of the current / next iteration
     v_dot(h, n, g.p(), hv.p(), gh);
@@ -173,14 +173,14 @@ static SolveResult cg(nsx_handle *h, const Op &A, double *x, const double *b, co
       it++;
       A(hv.p(), d.p());
       v_dot(h, n, d.p(), hv.p(), S_DH);
-      cg_update(h, n, x, d.p(), g.p(), hv.p(), gh, S_DH, S_RES);  // alpha = gh / (d.h); x += alpha d; g += alpha h; res = |g|
+      cg_update(h, n.n, x, d.p(), g.p(), hv.p(), gh, S_DH, S_RES);  // alpha = gh / (d.h); x += alpha d; g += alpha h; res = |g|
       r = std::sqrt(std::fabs(read_scalar(h, S_RES)));
       res.last = r;
       conv = sc_check(it, r, tol, maxiter);
       if (conv != 0) break;
       P(hv.p(), g.p());
       v_dot(h, n, g.p(), hv.p(), gh_new);
-      cg_direction(h, n, d.p(), hv.p(), gh_new, gh);  // beta = gh_new / gh_old ; d = beta d - h
+      cg_direction(h, n.n, d.p(), hv.p(), gh_new, gh);  // beta = gh_new / gh_old ; d = beta d - h
       std::swap(gh, gh_new);
     }
   }
@@ -189,7 +189,7 @@ static SolveResult cg(nsx_handle *h, const Op &A, double *x, const double *b, co
   return res;
 }
 
-static double norm2(nsx_handle *h, int n, const double *v) {
+static double norm2(nsx_handle *h, Span n, const double *v) {
   v_dot(h, n, v, v, S_T);
   return std::sqrt(read_scalar(h, S_T));
 }
@@ -241,36 +241,36 @@ static void count(nsx_solve_stats *st, bool F, const SolveResult &r) {
 
 void prec_vmult(nsx_handle *h, int type, double tol, int maxit, double *dst, const double *src, nsx_solve_stats *st) {
   if (!h->prec_ready) NSX_THROW(NSX_ERR_ARG, "preconditioner not initialised");
-  const int n_u = h->n_u, n_p = h->n_p, dim = h->dim;
-  const double *src_u = src, *src_p = src + n_u;
-  double *dst_u = dst, *dst_p = dst + n_u;
+  const int n_u = h->n_u, n_p = h->n_p, dim = h->dim, len_u = h->len_u, len_p = h->len_p;
+  const double *src_u = src, *src_p = src + h->off_p;
+  double *dst_u = dst, *dst_p = dst + h->off_p;
   Op Fm = [h](double *d, const double *s) { spmv_F(h, h->vF.p, s, d); };
   Op Sm = [h](double *d, const double *s) { spmv_S(h, s, d); };
   Op PF = [h, dim](double *d, const double *s) { ilu_solve(h, h->gA, h->schedF, h->luF.p, s, d, dim, "ilu_solve_F"); };
   Op PS = [h](double *d, const double *s) { ilu_solve(h, h->gS, h->schedS, h->luS.p, s, d, 1, "ilu_solve_S"); };
 
   if (type == NSX_PREC_YOSIDA) {  // Prec.hpp:365-408
-    Tmp yu(h, n_u), yp(h, n_p), tmp(h, n_p), tmp2(h, n_u), res(h, n_u);
+    Tmp yu(h, len_u), yp(h, len_p), tmp(h, len_p), tmp2(h, len_u), res(h, len_u);
     v_copy(h, n_u, yu.p(), src_u);                                                            // :375
     v_copy(h, n_p, yp.p(), src_p);                                                            // :376
-    count(st, true, gmres(h, Fm, yu.p(), src_u, PF, n_u, tol * norm2(h, n_u, src_u), maxit)); // :371-382
+    count(st, true, gmres(h, Fm, yu.p(), src_u, PF, n_u, len_u, tol * norm2(h, n_u, src_u), maxit)); // :371-382
     spmv_B(h, yu.p(), tmp.p());                                                               // :385
     v_add(h, n_p, tmp.p(), -1.0, src_p);                                                      // :386
-    count(st, false, cg(h, Sm, yp.p(), tmp.p(), PS, n_p, tol * norm2(h, n_p, tmp.p()), maxit));  // :388-390
+    count(st, false, cg(h, Sm, yp.p(), tmp.p(), PS, n_p, len_p, tol * norm2(h, n_p, tmp.p()), maxit));  // :388-390
     v_copy(h, n_p, dst_p, yp.p());                                                            // :394
     spmv_G(h, dst_p, tmp2.p(), false);                                                        // :398
     v_zero(h, n_u, res.p());                                                                  // :401
     v_copy(h, n_u, dst_u, yu.p());                                                            // :402
-    count(st, true, gmres(h, Fm, res.p(), tmp2.p(), PF, n_u, tol * norm2(h, n_u, tmp2.p()), maxit));  // :403-405
+    count(st, true, gmres(h, Fm, res.p(), tmp2.p(), PF, n_u, len_u, tol * norm2(h, n_u, tmp2.p()), maxit));  // :403-405
     v_sadd(h, n_u, dst_u, -1., 1., res.p());  // dst.block(0).sadd(-1,res): dst = -dst + res            :406
   } else if (type == NSX_PREC_SIMPLE) {  // Prec.hpp:151-205
-    Tmp sol1_u(h, n_u), sol1_p(h, n_p), temp_1(h, n_p), tmp(h, n_u);
+    Tmp sol1_u(h, len_u), sol1_p(h, len_p), temp_1(h, len_p), tmp(h, len_u);
     v_copy(h, n_u, sol1_u.p(), src_u);                                                             // :168
     v_copy(h, n_p, sol1_p.p(), src_p);                                                             // :169
-    count(st, true, gmres(h, Fm, sol1_u.p(), src_u, PF, n_u, tol * norm2(h, n_u, src_u), maxit));  // :157-173
+    count(st, true, gmres(h, Fm, sol1_u.p(), src_u, PF, n_u, len_u, tol * norm2(h, n_u, src_u), maxit));  // :157-173
     spmv_B(h, sol1_u.p(), temp_1.p());                                                             // :175
     v_add(h, n_p, temp_1.p(), -1.0, src_p);                                                        // :176
-    count(st, false, cg(h, Sm, sol1_p.p(), temp_1.p(), PS, n_p, tol * norm2(h, n_p, temp_1.p()), maxit));  // :179-182
+    count(st, false, cg(h, Sm, sol1_p.p(), temp_1.p(), PS, n_p, len_p, tol * norm2(h, n_p, temp_1.p()), maxit));  // :179-182
     v_copy(h, n_p, dst_p, sol1_p.p());                                                             // :194
     v_scale(h, n_p, dst_p, 1. / 0.5);                                                              // :195, alpha = 0.5 (:207)
     v_copy(h, n_u, dst_u, sol1_u.p());                                                             // :199
@@ -278,26 +278,26 @@ void prec_vmult(nsx_handle *h, int type, double tol, int maxit, double *dst, con
     v_scale_vec(h, n_u, tmp.p(), h->diag_D_inv.p);                                                 // :202
     v_add(h, n_u, dst_u, -1.0, tmp.p());                                                           // :203
   } else if (type == NSX_PREC_ASIMPLE) {  // Prec.hpp:254-311 (dst is the caller's vector: its content is the initial guess)
-    Tmp tmp_u(h, n_u), tmp_p(h, n_p);
-    count(st, true, gmres(h, Fm, dst_u, src_u, PF, n_u, tol * norm2(h, n_u, src_u), maxit));  // :271-273
+    Tmp tmp_u(h, len_u), tmp_p(h, len_p);
+    count(st, true, gmres(h, Fm, dst_u, src_u, PF, n_u, len_u, tol * norm2(h, n_u, src_u), maxit));  // :271-273
     spmv_B(h, dst_u, dst_p);                                                                   // :280
     v_sadd(h, n_p, dst_p, -1.0, 1.0, src_p);                                                   // :281
     v_copy(h, n_p, tmp_p.p(), dst_p);                                                          // :282
-    count(st, false, gmres(h, Sm, dst_p, tmp_p.p(), PS, n_p, tol * norm2(h, n_p, tmp_p.p()), maxit));  // :287-289
+    count(st, false, gmres(h, Sm, dst_p, tmp_p.p(), PS, n_p, len_p, tol * norm2(h, n_p, tmp_p.p()), maxit));  // :287-289
     v_scale_vec(h, n_u, dst_u, h->diag_D.p);                                                   // :294
     v_scale(h, n_p, dst_p, 1. / 1.0);                                                          // :298, alpha = 1 (:328)
     spmv_G(h, dst_p, tmp_u.p(), false);                                                        // :304
     v_add(h, n_u, dst_u, -1.0, tmp_u.p());                                                     // :305
     v_scale_vec(h, n_u, dst_u, h->diag_D_inv.p);                                               // :309
   } else if (type == NSX_PREC_AYOSIDA) {  // Prec.hpp:474-517
-    Tmp tmp(h, n_u), tmp2(h, n_p), yu(h, n_u), yp(h, n_p), t(h, n_u);
+    Tmp tmp(h, len_u), tmp2(h, len_p), yu(h, len_u), yp(h, len_p), t(h, len_u);
     v_copy(h, n_p, yp.p(), src_p);                    // :487
     v_copy(h, n_u, tmp.p(), src_u);                   // :491
     v_scale_vec(h, n_u, tmp.p(), h->diag_D_inv.p);    // :492
     v_copy(h, n_u, yu.p(), tmp.p());                  // :493
     spmv_B(h, tmp.p(), tmp2.p());                     // :496
     v_sadd(h, n_p, yp.p(), -1.0, 1.0, tmp2.p());      // :497
-    count(st, false, cg(h, Sm, dst_p, yp.p(), PS, n_p, tol * norm2(h, n_p, yp.p()), maxit));  // :500-502
+    count(st, false, cg(h, Sm, dst_p, yp.p(), PS, n_p, len_p, tol * norm2(h, n_p, yp.p()), maxit));  // :500-502
     v_copy(h, n_p, yp.p(), dst_p);                    // :504
     spmv_F(h, h->vF.p, yu.p(), t.p());                // :507 F->vmult(yu,yu): Epetra multiplies out of place when the arguments alias
     v_copy(h, n_u, yu.p(), t.p());
@@ -312,11 +312,11 @@ void prec_vmult(nsx_handle *h, int type, double tol, int maxit, double *dst, con
 
 void solve_time_step(nsx_handle *h, int type, double tol, double inner_rtol, int maxiter, int inner_maxiter, nsx_solve_stats *st) {
   HIP_CHECK(hipSetDevice(h->prm.device));
-  const int n = h->n_u + h->n_p;
+  const Span n = blk_span(h);
   nsx_solve_stats local;
   if (!st) st = &local;
   memset(st, 0, sizeof(*st));
-  v_copy(h, n, h->prev_sol.p, h->sol.p);  // previous_solution = solution (NS3D.cpp:555)
+  v_copy(h, h->len_blk, h->prev_sol.p, h->sol.p);  // previous_solution = solution (NS3D.cpp:555)
   HIP_CHECK(hipStreamSynchronize(h->stream));
   double t0 = now_s();
   prec_initialize(h, type);  // NS3D.cpp:568-569
@@ -325,8 +325,10 @@ void solve_time_step(nsx_handle *h, int type, double tol, double inner_rtol, int
   t0 = now_s();
   Op A = [h](double *d, const double *s) { spmv_saddle(h, s, d); };
   Op P = [h, type, inner_rtol, inner_maxiter, st](double *d, const double *s) { prec_vmult(h, type, inner_rtol, inner_maxiter, d, s, st); };
-  SolveResult r = gmres(h, A, h->sol_owned.p, h->rhs.p, P, n, tol, maxiter);  // NS3D.cpp:574
-  v_copy(h, n, h->sol.p, h->sol_owned.p);  // solution = solution_owned (NS3D.cpp:638)
+  SolveResult r = gmres(h, A, h->sol_owned.p, h->rhs.p, P, n, h->len_blk, tol, maxiter);  // NS3D.cpp:574
+  v_copy(h, h->len_blk, h->sol.p, h->sol_owned.p);  // solution = solution_owned (NS3D.cpp:638): copy + ghost import
+  comm_halo_u(h, h->sol.p);
+  comm_halo_p(h, h->sol.p + h->off_p);
   HIP_CHECK(hipStreamSynchronize(h->stream));
   st->t_solve = now_s() - t0;
   st->outer_iterations = r.steps;
@@ -382,6 +384,7 @@ int nsx_prec_initialize(nsx_handle *h, int prec_type) {
 int nsx_prec_vmult(nsx_handle *h, int prec_type, double inner_rtol, int inner_maxiter, double *dst, const double *src, nsx_solve_stats *stats) {
   NSX_API_BODY(h, {
     if (!dst || !src) NSX_THROW(NSX_ERR_ARG, "null vector");
+    if (h->dist) NSX_THROW(NSX_ERR_UNSUPPORTED, "nsx_prec_vmult with host vectors works on a single-process handle only");
     HIP_CHECK(hipSetDevice(h->prm.device));
     const int n = h->n_u + h->n_p;
     nsx::Tmp d(h, n), s(h, n);
@@ -398,12 +401,17 @@ int nsx_system_vmult(nsx_handle *h, double *dst, const double *src) {
   NSX_API_BODY(h, {
     if (!dst || !src || !h->assembled) NSX_THROW(NSX_ERR_ARG, "null vector / nothing assembled");
     HIP_CHECK(hipSetDevice(h->prm.device));
-    const int n = h->n_u + h->n_p;
-    nsx::Tmp d(h, n), s(h, n);
-    HIP_CHECK(hipMemcpyAsync(s.p(), src, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    nsx::Tmp d(h, h->len_blk), s(h, h->len_blk);
+    // host vectors are globally indexed: pick the owned entries (ghosts come through the halo exchange of the product)
+    std::vector<double> loc(h->len_blk, 0.0);
+    for (int i = 0; i < h->n_u; ++i) loc[i] = src[(size_t)h->dim * h->goff_u + i];
+    for (int i = 0; i < h->n_p; ++i) loc[h->off_p + i] = src[(size_t)h->n_u_glob + h->goff_p + i];
+    HIP_CHECK(hipMemcpyAsync(s.p(), loc.data(), loc.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     nsx::spmv_saddle(h, s.p(), d.p());
-    HIP_CHECK(hipMemcpyAsync(dst, d.p(), (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipMemcpyAsync(loc.data(), d.p(), loc.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < h->n_u; ++i) dst[(size_t)h->dim * h->goff_u + i] = loc[i];
+    for (int i = 0; i < h->n_p; ++i) dst[(size_t)h->n_u_glob + h->goff_p + i] = loc[h->off_p + i];
   })
 }
 
@@ -411,6 +419,7 @@ int nsx_ilu_apply(nsx_handle *h, int which, double *dst, const double *src) {
   NSX_API_BODY(h, {
     if (!dst || !src || which < 0 || which > 1) NSX_THROW(NSX_ERR_ARG, "bad arguments");
     if (!h->prec_ready) NSX_THROW(NSX_ERR_ARG, "no factors: call nsx_prec_initialize first");
+    if (h->dist) NSX_THROW(NSX_ERR_UNSUPPORTED, "nsx_ilu_apply with host vectors works on a single-process handle only");
     HIP_CHECK(hipSetDevice(h->prm.device));
     const int n = which == 0 ? h->n_u : h->n_p;
     nsx::Tmp d(h, n), s(h, n);

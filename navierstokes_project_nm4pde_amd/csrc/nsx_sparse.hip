@@ -142,6 +142,7 @@ static double bytes_vel(nsx_handle *h, bool with_g) {
 }
 
 void spmv_F(nsx_handle *h, const double *vals, const double *x, double *y) {
+  comm_halo_u(h, x);
   LaunchScope ls(h, "spmv_F", bytes_vel(h, false));
   static const int Wsel = getenv("NSX_SPMV_W") ? atoi(getenv("NSX_SPMV_W")) : 16;
 #define NSX_SPMV(D, W_)                                                                                                          \
@@ -155,7 +156,12 @@ void spmv_F(nsx_handle *h, const double *vals, const double *x, double *y) {
 #undef NSX_SPMV
 }
 
+static void spmv_B_nohalo(nsx_handle *h, const double *xu, double *yp);
 void spmv_B(nsx_handle *h, const double *xu, double *yp) {
+  comm_halo_u(h, xu);
+  spmv_B_nohalo(h, xu, yp);
+}
+static void spmv_B_nohalo(nsx_handle *h, const double *xu, double *yp) {
   LaunchScope ls(h, "spmv_B", (4.0 + 8.0 * h->dim) * h->gB.nnz() + 12.0 * h->NP + 8.0 * h->dim * h->N2);
   const int W = 64, grid = cdiv((int64_t)h->NP * W, 256);
   if (h->dim == 2)
@@ -166,6 +172,7 @@ void spmv_B(nsx_handle *h, const double *xu, double *yp) {
 }
 
 void spmv_G(nsx_handle *h, const double *xp, double *yu, bool accumulate) {
+  comm_halo_p(h, xp);
   LaunchScope ls(h, "spmv_G", (4.0 + 8.0 * h->dim) * h->gG.nnz() + (double)h->N2 * (4 + 8.0 * h->dim) + 8.0 * h->NP);
   const int W = 8, grid = cdiv((int64_t)h->N2 * W, 256);
   if (h->dim == 2)
@@ -178,20 +185,23 @@ void spmv_G(nsx_handle *h, const double *xp, double *yu, bool accumulate) {
 
 // BlockSparseMatrix::vmult: y_u = F x_u + block(0,1) x_p ; y_p = block(1,0) x_u  (block (1,1) has an empty pattern)
 void spmv_saddle(nsx_handle *h, const double *x, double *y) {
+  comm_halo_u(h, x);
+  comm_halo_p(h, x + h->off_p);
   {
     LaunchScope ls(h, "spmv_saddle_u", bytes_vel(h, true));
     const int W = 16, grid = (cdiv((int64_t)h->N2 * W, 256) + 7) & ~7;
     if (h->dim == 2)
       hipLaunchKernelGGL((k_spmv_vel<2, W, true>), dim3(grid), dim3(256), 0, h->stream, h->N2, h->gA.rowptr.p, h->gA.colind.p, h->vF.p, x,
-                         h->gG.rowptr.p, h->gG.colind.p, h->vG.p, x + h->n_u, y);
+                         h->gG.rowptr.p, h->gG.colind.p, h->vG.p, x + h->off_p, y);
     else
       hipLaunchKernelGGL((k_spmv_vel<3, W, true>), dim3(grid), dim3(256), 0, h->stream, h->N2, h->gA.rowptr.p, h->gA.colind.p, h->vF.p, x,
-                         h->gG.rowptr.p, h->gG.colind.p, h->vG.p, x + h->n_u, y);
+                         h->gG.rowptr.p, h->gG.colind.p, h->vG.p, x + h->off_p, y);
   }
-  spmv_B(h, x, y + h->n_u);
+  spmv_B_nohalo(h, x, y + h->off_p);
 }
 
 void spmv_S(nsx_handle *h, const double *x, double *y) {
+  comm_halo_p(h, x);
   LaunchScope ls(h, "spmv_S", 12.0 * h->gS.nnz() + 20.0 * h->NP);
   const int W = 32;
   hipLaunchKernelGGL((k_spmv_csr<W>), dim3(cdiv((int64_t)h->NP * W, 256)), dim3(256), 0, h->stream, h->NP, h->gS.rowptr.p,
@@ -265,6 +275,7 @@ __global__ __launch_bounds__(64) void k_schur(int n_rows, const int32_t *__restr
 }
 
 void schur_numeric(nsx_handle *h, const double *w) {
+  comm_halo_u(h, w);  // weights of ghost velocity dofs
   int max_row = 0;
   const Csr &B = h->gB.host;
   for (int i = 0; i < B.n_rows; ++i) max_row = std::max(max_row, B.rowptr[i + 1] - B.rowptr[i]);

@@ -176,6 +176,46 @@ class DoFs:
         rowptr = _arr(rp, (n + 1,), np.int32)
         return rowptr, _arr(ci, (int(rowptr[-1]),), np.int32)
 
+    def rank_view(self, rank, world):
+        """Per-GPU view (owned + two ghost layers of cells, halo plan) for a run with `world` processes."""
+        L = self._lib
+        vp = C.c_void_p
+        if not getattr(L, "_rv_ready", False):
+            L.nsxh_rank_view_create.restype = vp
+            L.nsxh_rank_view_create.argtypes = [vp, C.c_int, C.c_int]
+            L.nsxh_rank_view_free.argtypes = [vp]
+            for name in ("n_cells", "n_cells_layer1", "n_virtual_ranks", "n_neighbors"):
+                f = getattr(L, "nsxh_rank_view_" + name)
+                f.restype, f.argtypes = C.c_int, [vp]
+            for name in ("cell_ids", "cell_dofs", "gpu_u_ptr", "gpu_p_ptr", "rank_u_ptr", "rank_p_ptr", "neighbors",
+                         "send_u_ptr", "send_u_nodes", "send_p_ptr", "send_p_nodes"):
+                f = getattr(L, "nsxh_rank_view_" + name)
+                f.restype, f.argtypes = _i32p, [vp]
+            L.nsxh_rank_view_cell_coords.restype = _f64p
+            L.nsxh_rank_view_cell_coords.argtypes = [vp]
+            L._rv_ready = True
+        v = L.nsxh_rank_view_create(self._h, rank, world)
+        if not v:
+            raise ValueError("rank view needs n_subdomains to be a multiple of world")
+        nc, nn, ns = L.nsxh_rank_view_n_cells(v), L.nsxh_rank_view_n_neighbors(v), L.nsxh_rank_view_n_virtual_ranks(v)
+        out = {
+            "rank": rank, "world": world, "n_cells": nc, "n_cells_layer1": L.nsxh_rank_view_n_cells_layer1(v),
+            "cell_ids": _arr(L.nsxh_rank_view_cell_ids(v), (nc,), np.int32),
+            "cell_dofs": _arr(L.nsxh_rank_view_cell_dofs(v), (nc, self.dofs_per_cell), np.int32),
+            "cell_coords": _arr(L.nsxh_rank_view_cell_coords(v), (nc, self.dim + 1, self.dim), np.float64),
+            "gpu_u_ptr": _arr(L.nsxh_rank_view_gpu_u_ptr(v), (world + 1,), np.int32),
+            "gpu_p_ptr": _arr(L.nsxh_rank_view_gpu_p_ptr(v), (world + 1,), np.int32),
+            "rank_u_ptr": _arr(L.nsxh_rank_view_rank_u_ptr(v), (ns + 1,), np.int32),
+            "rank_p_ptr": _arr(L.nsxh_rank_view_rank_p_ptr(v), (ns + 1,), np.int32),
+            "neighbors": _arr(L.nsxh_rank_view_neighbors(v), (nn,), np.int32),
+            "send_u_ptr": _arr(L.nsxh_rank_view_send_u_ptr(v), (nn + 1,), np.int32),
+            "send_p_ptr": _arr(L.nsxh_rank_view_send_p_ptr(v), (nn + 1,), np.int32),
+        }
+        out["send_u_nodes"] = _arr(L.nsxh_rank_view_send_u_nodes(v), (int(out["send_u_ptr"][-1]),), np.int32)
+        out["send_p_nodes"] = _arr(L.nsxh_rank_view_send_p_nodes(v), (int(out["send_p_ptr"][-1]),), np.int32)
+        L.nsxh_rank_view_free(v)
+        return out
+
     def __del__(self):
         try:
             self._lib.nsxh_dofs_free(self._h)

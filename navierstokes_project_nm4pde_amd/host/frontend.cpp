@@ -978,3 +978,140 @@ const double *nsxh_tables_N1(const nsxh_tables *t) { return t->N1.data(); }
 const double *nsxh_tables_dN1(const nsxh_tables *t) { return t->dN1.data(); }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------- per-rank view for multi-GPU runs
+// One GPU = n_sub consecutive subdomains ("virtual ranks").  A rank keeps every cell that touches one of its owned
+// P2 nodes (layer 1: enough to assemble all owned rows without any exchange, replacing compress(VectorOperation::add),
+// reference NavierStokes3D.cpp:314-319,506-511) plus the cells touching a node of those (layer 2: makes the rows of
+// block(1,0) complete for every ghost pressure node the Schur product B D^-1 B^T of an owned row can reach).
+// The halo plan (what Epetra_Import does inside every vmult) is computed from the replicated serial mesh, exactly as
+// the reference replicates it on every rank before partitioning (NavierStokes3D.cpp:8-19): no setup communication.
+struct nsxh_rank_view {
+  int rank = 0, world = 1, dim = 0, dpc = 0, n_cells = 0, n_cells_layer1 = 0;
+  std::vector<int32_t> cell_ids, cell_dofs, gpu_u_ptr, gpu_p_ptr, rank_u_ptr, rank_p_ptr;
+  std::vector<double> cell_coords;
+  std::vector<int32_t> nbr, send_u_ptr, send_u_nodes, send_p_ptr, send_p_nodes;
+};
+
+namespace {
+
+struct LocalSets {
+  std::vector<int32_t> cells1, cells2;      // layer-1 / extra layer-2 cells (ascending)
+  std::vector<int32_t> nodes2, nodes1;      // all local P2 / P1 nodes (sorted global ids)
+};
+
+LocalSets local_sets(const nsxh_dofs *d, int32_t u0, int32_t u1) {
+  const int dim = d->dim, nv = dim + 1, np2 = nv + (dim == 2 ? 3 : 6);
+  const int nc = d->n_cells;
+  LocalSets s;
+  std::vector<char> node_in(d->n2, 0), cell_in(nc, 0);
+  for (int c = 0; c < nc; ++c) {
+    const int32_t *cn = d->cell_nodes2.data() + (size_t)c * np2;
+    bool own = false;
+    for (int a = 0; a < np2 && !own; ++a) own = cn[a] >= u0 && cn[a] < u1;
+    if (own) {
+      cell_in[c] = 1;
+      s.cells1.push_back(c);
+    }
+  }
+  for (int32_t c : s.cells1)
+    for (int a = 0; a < np2; ++a) node_in[d->cell_nodes2[(size_t)c * np2 + a]] = 1;
+  for (int c = 0; c < nc; ++c) {
+    if (cell_in[c]) continue;
+    const int32_t *cn = d->cell_nodes2.data() + (size_t)c * np2;
+    bool touch = false;
+    for (int a = 0; a < np2 && !touch; ++a) touch = node_in[cn[a]];
+    if (touch) {
+      cell_in[c] = 2;
+      s.cells2.push_back(c);
+    }
+  }
+  std::vector<char> n2(d->n2, 0), n1(d->n1, 0);
+  for (int c = 0; c < nc; ++c) {
+    if (!cell_in[c]) continue;
+    for (int a = 0; a < np2; ++a) n2[d->cell_nodes2[(size_t)c * np2 + a]] = 1;
+    for (int v = 0; v < nv; ++v) n1[d->cell_nodes1[(size_t)c * nv + v]] = 1;
+  }
+  for (int32_t i = 0; i < d->n2; ++i)
+    if (n2[i]) s.nodes2.push_back(i);
+  for (int32_t i = 0; i < d->n1; ++i)
+    if (n1[i]) s.nodes1.push_back(i);
+  return s;
+}
+
+}  // namespace
+
+extern "C" {
+
+nsxh_rank_view *nsxh_rank_view_create(const nsxh_dofs *d, int rank, int world) {
+  if (world < 1 || rank < 0 || rank >= world || d->n_sub % world) return nullptr;
+  const int n_sub = d->n_sub / world, dim = d->dim, nv = dim + 1;
+  auto *v = new nsxh_rank_view;
+  v->rank = rank;
+  v->world = world;
+  v->dim = dim;
+  v->dpc = d->dpc;
+  for (int r = 0; r <= world; ++r) {
+    v->gpu_u_ptr.push_back(d->owned_u_ptr[(size_t)r * n_sub]);
+    v->gpu_p_ptr.push_back(d->owned_p_ptr[(size_t)r * n_sub]);
+  }
+  for (int s = 0; s <= n_sub; ++s) {
+    v->rank_u_ptr.push_back(d->owned_u_ptr[(size_t)rank * n_sub + s]);
+    v->rank_p_ptr.push_back(d->owned_p_ptr[(size_t)rank * n_sub + s]);
+  }
+  LocalSets mine = local_sets(d, v->gpu_u_ptr[rank], v->gpu_u_ptr[rank + 1]);
+  v->n_cells_layer1 = (int)mine.cells1.size();
+  v->cell_ids = mine.cells1;
+  v->cell_ids.insert(v->cell_ids.end(), mine.cells2.begin(), mine.cells2.end());
+  v->n_cells = (int)v->cell_ids.size();
+  v->cell_dofs.reserve((size_t)v->n_cells * d->dpc);
+  v->cell_coords.reserve((size_t)v->n_cells * nv * dim);
+  for (int32_t c : v->cell_ids) {
+    v->cell_dofs.insert(v->cell_dofs.end(), d->cell_dofs.begin() + (size_t)c * d->dpc, d->cell_dofs.begin() + (size_t)(c + 1) * d->dpc);
+    v->cell_coords.insert(v->cell_coords.end(), d->cell_coords.begin() + (size_t)c * nv * dim,
+                          d->cell_coords.begin() + (size_t)(c + 1) * nv * dim);
+  }
+  // send lists: what every other rank's local set contains of MY nodes (sorted by global id = the order in which the
+  // receiver stores its ghosts)
+  v->send_u_ptr.push_back(0);
+  v->send_p_ptr.push_back(0);
+  for (int s = 0; s < world; ++s) {
+    if (s == rank) continue;
+    LocalSets other = local_sets(d, v->gpu_u_ptr[s], v->gpu_u_ptr[s + 1]);
+    std::vector<int32_t> su, sp;
+    for (int32_t n : other.nodes2)
+      if (n >= v->gpu_u_ptr[rank] && n < v->gpu_u_ptr[rank + 1]) su.push_back(n);
+    for (int32_t n : other.nodes1)
+      if (n >= v->gpu_p_ptr[rank] && n < v->gpu_p_ptr[rank + 1]) sp.push_back(n);
+    // a neighbour is also a rank I receive from, even if I send it nothing
+    bool recv_from = false;
+    for (int32_t n : mine.nodes2) recv_from = recv_from || (n >= v->gpu_u_ptr[s] && n < v->gpu_u_ptr[s + 1]);
+    for (int32_t n : mine.nodes1) recv_from = recv_from || (n >= v->gpu_p_ptr[s] && n < v->gpu_p_ptr[s + 1]);
+    if (su.empty() && sp.empty() && !recv_from) continue;
+    v->nbr.push_back(s);
+    v->send_u_nodes.insert(v->send_u_nodes.end(), su.begin(), su.end());
+    v->send_p_nodes.insert(v->send_p_nodes.end(), sp.begin(), sp.end());
+    v->send_u_ptr.push_back((int32_t)v->send_u_nodes.size());
+    v->send_p_ptr.push_back((int32_t)v->send_p_nodes.size());
+  }
+  return v;
+}
+void nsxh_rank_view_free(nsxh_rank_view *v) { delete v; }
+int nsxh_rank_view_n_cells(const nsxh_rank_view *v) { return v->n_cells; }
+int nsxh_rank_view_n_cells_layer1(const nsxh_rank_view *v) { return v->n_cells_layer1; }
+const int32_t *nsxh_rank_view_cell_ids(const nsxh_rank_view *v) { return v->cell_ids.data(); }
+const int32_t *nsxh_rank_view_cell_dofs(const nsxh_rank_view *v) { return v->cell_dofs.data(); }
+const double *nsxh_rank_view_cell_coords(const nsxh_rank_view *v) { return v->cell_coords.data(); }
+const int32_t *nsxh_rank_view_gpu_u_ptr(const nsxh_rank_view *v) { return v->gpu_u_ptr.data(); }
+const int32_t *nsxh_rank_view_gpu_p_ptr(const nsxh_rank_view *v) { return v->gpu_p_ptr.data(); }
+int nsxh_rank_view_n_virtual_ranks(const nsxh_rank_view *v) { return (int)v->rank_u_ptr.size() - 1; }
+const int32_t *nsxh_rank_view_rank_u_ptr(const nsxh_rank_view *v) { return v->rank_u_ptr.data(); }
+const int32_t *nsxh_rank_view_rank_p_ptr(const nsxh_rank_view *v) { return v->rank_p_ptr.data(); }
+int nsxh_rank_view_n_neighbors(const nsxh_rank_view *v) { return (int)v->nbr.size(); }
+const int32_t *nsxh_rank_view_neighbors(const nsxh_rank_view *v) { return v->nbr.data(); }
+const int32_t *nsxh_rank_view_send_u_ptr(const nsxh_rank_view *v) { return v->send_u_ptr.data(); }
+const int32_t *nsxh_rank_view_send_u_nodes(const nsxh_rank_view *v) { return v->send_u_nodes.data(); }
+const int32_t *nsxh_rank_view_send_p_ptr(const nsxh_rank_view *v) { return v->send_p_ptr.data(); }
+const int32_t *nsxh_rank_view_send_p_nodes(const nsxh_rank_view *v) { return v->send_p_nodes.data(); }
+
+}  // extern "C"

@@ -23,8 +23,12 @@ API = [
     "nsx_solve_time_step", "nsx_prec_initialize", "nsx_prec_vmult", "nsx_system_vmult", "nsx_ilu_apply",
     "nsx_export_block", "nsx_schur_nnz", "nsx_schur_get", "nsx_scalar_graph_nnz", "nsx_scalar_graph", "nsx_ilu_get",
     "nsx_profile_enable", "nsx_profile_reset", "nsx_profile_count", "nsx_profile_get", "nsx_comm_unique_id",
-    "nsx_comm_init", "nsx_set_mesh_distributed",
+    "nsx_comm_init", "nsx_comm_init_callbacks", "nsx_set_mesh_distributed",
 ]
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _f64p, C.c_int)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(_f64p), C.POINTER(C.c_int),
+                          C.POINTER(_f64p), C.POINTER(C.c_int))
 
 
 class Params(C.Structure):
@@ -83,6 +87,9 @@ def lib():
     L.nsx_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), _f64p, _f64p]
     L.nsx_comm_unique_id.argtypes = [C.POINTER(C.c_uint8)]
     L.nsx_comm_init.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_uint8)]
+    L.nsx_comm_init_callbacks.argtypes = [vp, C.c_int, C.c_int, ALLREDUCE_FN, EXCHANGE_FN, C.c_void_p]
+    L.nsx_set_mesh_distributed.argtypes = [vp, C.c_int, C.c_int, C.c_int, _i32p, _f64p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           _i32p, _i32p, C.c_int, _i32p, _i32p, _i32p, _i32p, _i32p]
     L._nsx_ready = True
     return L
 
@@ -103,10 +110,41 @@ def _cd(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
+def gloo_callbacks():
+    """Host-buffer communicator callbacks on torch.distributed (any backend with CPU tensors, e.g. gloo)."""
+    import torch
+    import torch.distributed as dist
+
+    def allreduce(ctx, buf, count):
+        t = torch.from_numpy(np.ctypeslib.as_array(buf, shape=(count,)))
+        dist.all_reduce(t)
+        return 0
+
+    def exchange(ctx, n, ranks, send, scount, recv, rcount):
+        reqs, keep = [], []
+        for k in range(n):
+            if rcount[k]:
+                t = torch.from_numpy(np.ctypeslib.as_array(recv[k], shape=(rcount[k],)))
+                keep.append(t)
+                reqs.append(dist.irecv(t, src=int(ranks[k])))
+            if scount[k]:
+                t = torch.from_numpy(np.ctypeslib.as_array(send[k], shape=(scount[k],)).copy())
+                keep.append(t)
+                reqs.append(dist.isend(t, dst=int(ranks[k])))
+        for q in reqs:
+            q.wait()
+        return 0
+
+    return ALLREDUCE_FN(allreduce), EXCHANGE_FN(exchange)
+
+
 class Nsx:
     """One device-side `NavierStokes` problem (a handle of libnsx)."""
 
-    def __init__(self, dofs, tables, nu, deltat, device=0):
+    def __init__(self, dofs, tables, nu, deltat, device=0, rank=0, world=1, comm="rccl"):
+        """world == 1: the whole problem on one GPU.  world > 1: this process holds rank `rank` of a run with one
+        process per GPU (mesh partitioned with Mesh.partition(world, n_sub)); `comm` = "rccl" (needs an initialised
+        torch.distributed group to broadcast the unique id) or "callbacks" (host buffers over torch.distributed)."""
         L = lib()
         self.L = L
         self._h = C.c_void_p()
@@ -117,12 +155,49 @@ class Nsx:
         self.dim, self.n_u, self.n_p = dofs.dim, dofs.n_u, dofs.n_p
         self.n = self.n_u + self.n_p
         self.dofs = dofs
+        self.rank, self.world = rank, world
         N2, dN2, N1, w = _cd(tables.N2), _cd(tables.dN2), _cd(tables.N1), _cd(tables.weights)
         self._ck(L.nsx_set_tables(self._h, tables.n_q, tables.n_p2, tables.n_p1, _d(N2), _d(dN2), _d(N1), _d(w)))
-        cd, cc = _ci(dofs.cell_dofs), _cd(dofs.cell_coords)
-        self._ck(L.nsx_set_mesh(self._h, dofs.n_cells, dofs.dofs_per_cell, _i(cd), _d(cc), dofs.n_u, dofs.n_p))
-        if dofs.n_subdomains > 1:
-            self.set_ranks(dofs.owned_u_ptr, dofs.owned_p_ptr)
+        if world == 1:
+            cd, cc = _ci(dofs.cell_dofs), _cd(dofs.cell_coords)
+            self._ck(L.nsx_set_mesh(self._h, dofs.n_cells, dofs.dofs_per_cell, _i(cd), _d(cc), dofs.n_u, dofs.n_p))
+            if dofs.n_subdomains > 1:
+                self.set_ranks(dofs.owned_u_ptr, dofs.owned_p_ptr)
+            return
+        v = dofs.rank_view(rank, world)
+        self.view = v
+        cd, cc = _ci(v["cell_dofs"]), _cd(v["cell_coords"])
+        arrs = [_ci(v[k]) for k in ("gpu_u_ptr", "gpu_p_ptr", "neighbors", "send_u_ptr", "send_u_nodes", "send_p_ptr", "send_p_nodes")]
+        self._ck(L.nsx_set_mesh_distributed(self._h, v["n_cells"], v["n_cells_layer1"], dofs.dofs_per_cell, _i(cd), _d(cc),
+                                            dofs.n_u, dofs.n_p, world, rank, _i(arrs[0]), _i(arrs[1]), len(arrs[2]), _i(arrs[2]),
+                                            _i(arrs[3]), _i(arrs[4]), _i(arrs[5]), _i(arrs[6])))
+        self.set_ranks(v["rank_u_ptr"], v["rank_p_ptr"])
+        if comm == "callbacks":
+            self._cb = gloo_callbacks()           # keep the CFUNCTYPE objects alive
+            self._ck(L.nsx_comm_init_callbacks(self._h, rank, world, self._cb[0], self._cb[1], None))
+        else:
+            import torch.distributed as dist
+            ident = (C.c_uint8 * 128)()
+            if rank == 0:
+                self._ck(L.nsx_comm_unique_id(ident))
+            box = [bytes(ident)]
+            dist.broadcast_object_list(box, src=0)
+            ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
+            self._ck(L.nsx_comm_init(self._h, rank, world, ident))
+
+    def gather_solution(self):
+        """Global solution vector on every rank (owned parts summed over the process group)."""
+        x = np.zeros(self.n)
+        self._ck(self.L.nsx_get_solution(self._h, _d(x)))
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            t = torch.from_numpy(x)
+            if dist.get_backend() == "nccl":
+                t = t.cuda()
+            dist.all_reduce(t)
+            x = t.cpu().numpy()
+        return x
 
     def _ck(self, rc):
         if rc:
@@ -155,7 +230,7 @@ class Nsx:
         self._ck(self.L.nsx_set_solution(self._h, _d(v)))
 
     def _get(self, fn):
-        v = np.empty(self.n)
+        v = np.zeros(self.n)
         self._ck(fn(self._h, _d(v)))
         return v
 
@@ -210,7 +285,7 @@ class Nsx:
 
     def system_vmult(self, src):
         src = _cd(src)
-        dst = np.empty_like(src)
+        dst = np.zeros_like(src)
         self._ck(self.L.nsx_system_vmult(self._h, _d(dst), _d(src)))
         return dst
 
