@@ -9,9 +9,9 @@ region starts; VTU output and forces are excluded.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--level L] [--ranks R] [--schur-blocks S]
 
-For N > 1 the driver launches one process per GPU with torch.distributed.run (RCCL).  This round every rank
-advances its own replica of the workload ("replicas only": the owned+ghost distributed mesh path is not
-finished), so per-GPU work is fixed and `scaling` is "weak".
+For N > 1 the driver launches one process per GPU with torch.distributed.run.  The SAME mesh is partitioned over the
+N GPUs (owned rows + ghost layers per rank, RCCL halo exchange of ghost DoFs inside every SpMV, RCCL all-reduce of
+every dot product, per-rank ILU(0) exactly as the reference's MPI run): total work is fixed, `scaling` is "strong".
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -25,24 +25,46 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
+# scope name used by the library's HIP-event timer -> kernel symbol in rocprofv3 output
+KERNEL_OF = {"add_and_dot": "void nsx::k_reduce<1>", "dot": "void nsx::k_reduce<0>", "spmv_F": "void nsx::k_spmv_vel<3, 16, false>",
+             "ilu_solve_F": "void nsx::k_ilu_solve_packed<3, 16, 8>", "ilu_solve_S": "void nsx::k_ilu_solve_packed<1, 32, 8>",
+             "axpby": "nsx::k_axpby", "spmv_S": "void nsx::k_spmv_csr<32>"}
 
-def build_problem(level, ranks):
+
+def pmc_traffic(scope):
+    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same command (FETCH_SIZE and
+    WRITE_SIZE in separate passes, values in KiB; gfx950 FETCH_SIZE counts 64 B per 128-B request, so it is doubled:
+    /opt/skills/guides/MI355X_MICROARCH.md section HBM).  None when no profile is committed for the kernel."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_per_kernel.json")
+    try:
+        with open(path) as f:
+            tab = json.load(f)
+        e = tab[KERNEL_OF[scope]]
+        return (2.0 * e["FETCH_SIZE_KB_avg"] + e["WRITE_SIZE_KB_avg"]) * 1024.0
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def build_problem(level, ranks, world=1):
     from navierstokes_project_nm4pde_amd.frontend import DoFs, Mesh, Tables
-    mesh = Mesh.cylinder(3, level).partition(1, ranks)
+    mesh = Mesh.cylinder(3, level).partition(world, max(1, ranks // world))
     return mesh, DoFs(mesh), Tables(3)
 
 
-def gpu_run(dofs, tables, steps, warmup, schur_blocks, device, profile_steps=2, barrier=None):
+def gpu_run(dofs, tables, steps, warmup, schur_blocks, device, profile_steps=2, barrier=None, rank=0, world=1):
     import numpy as np
     from navierstokes_project_nm4pde_amd import nsx
     from navierstokes_project_nm4pde_amd.problem import InletVelocity, cylinder_boundary_values
     nu, dt = 1e-3, 2e-4
-    dev = nsx.Nsx(dofs, tables, nu, dt, device=device)
+    dev = nsx.Nsx(dofs, tables, nu, dt, device=device, rank=rank, world=world, comm="rccl")
     if schur_blocks and schur_blocks < dofs.n_subdomains:
-        stride = max(1, dofs.n_subdomains // schur_blocks)
-        ptr = list(dofs.owned_p_ptr[::stride])
-        if ptr[-1] != dofs.n_p:
-            ptr.append(dofs.n_p)
+        # coarser ILU blocks for the Schur matrix: unions of consecutive virtual ranks (of this GPU)
+        n_sub = dofs.n_subdomains // world
+        mine = dofs.owned_p_ptr[rank * n_sub:(rank + 1) * n_sub + 1]
+        stride = max(1, n_sub // max(1, schur_blocks // world))
+        ptr = list(mine[::stride])
+        if ptr[-1] != mine[-1]:
+            ptr.append(mine[-1])
         dev.set_schur_blocks(np.array(ptr, dtype=np.int32))
     inlet = InletVelocity(3)  # test case 2, u_m = 9 (reference NavierStokes3D.hpp:37,80)
     dev.set_solution(np.zeros(dofs.n_dofs))  # u_0 = 0 (reference NavierStokes3D.hpp:200)
@@ -123,6 +145,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "NSX_BENCH_DEVICE" in os.environ:  # development only: several ranks on one card
+        local_rank = int(os.environ["NSX_BENCH_DEVICE"])
     import torch
     barrier = None
     if world > 1:
@@ -136,9 +160,10 @@ def main():
         def barrier():
             torch.cuda.synchronize()
 
-    mesh, dofs, tables = build_problem(args.level, args.ranks)
+    mesh, dofs, tables = build_problem(args.level, args.ranks, world)
+    # profiling pass on all ranks (collective calls inside the solve must match on every rank)
     elapsed, stats, table = gpu_run(dofs, tables, args.steps, args.warmup, args.schur_blocks, local_rank,
-                                    profile_steps=2 if rank == 0 else 0, barrier=barrier)
+                                    profile_steps=2, barrier=barrier, rank=rank, world=world)
     if world > 1:
         import torch.distributed as dist
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -149,7 +174,7 @@ def main():
             torch.distributed.destroy_process_group()
         return
 
-    steps_per_s = world * args.steps / elapsed
+    steps_per_s = args.steps / elapsed  # one partitioned problem: the whole job advances `steps` time steps
     outer = sum(s["outer_iterations"] for s in stats)
     t_solve = sum(s["t_solve"] for s in stats)
     # roofline of the dominant kernel (by summed HIP-event time over the profiled steps)
@@ -169,19 +194,21 @@ def main():
     if dom:
         a = kernels[dom]["alg_GBps"]
         roof = {"kernel": dom, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
-                "traffic": None, "avg_us": kernels[dom]["avg_us"], "share_of_kernel_time": kernels[dom]["share"]}
+                "traffic": pmc_traffic(dom), "algorithmic_bytes": table[dom]["bytes_per_launch"],
+                "avg_us": kernels[dom]["avg_us"], "share_of_kernel_time": kernels[dom]["share"]}
         if "spmv_F" in kernels and kernels["spmv_F"]["alg_GBps"]:
             roof["spmv_F_GBps"] = kernels["spmv_F"]["alg_GBps"]
             roof["spmv_F_frac"] = kernels["spmv_F"]["alg_GBps"] / HBM_PEAK_GBS
     out = {
         "metric": "time-steps/sec (assemble_time_step + solve_time_step), 3D flow past a cylinder, P2/P1, Yosida",
         "value": steps_per_s, "unit": "time-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic (block-structured tetrahedral cylinder mesh, u0 = 0, reference inlet profile)",
         "config": {"workload": "3D flow-past-cylinder, P2/P1 (reference FE_SimplexP), %d DoF, %d cells, dt=2e-4, nu=1e-3, u_m=9, "
                                "GMRES(1e-4 abs)+Yosida(inner 1e-2), ILU(0) per rank with %d ranks (Schur: %d blocks)"
                                % (dofs.n_dofs, dofs.n_cells, args.ranks, args.schur_blocks),
-                   "n_dofs": dofs.n_dofs, "n_cells": dofs.n_cells, "mode": "replicas" if world > 1 else "single"},
+                   "n_dofs": dofs.n_dofs, "n_cells": dofs.n_cells,
+                   "parallelism": "mesh partitioned over %d GPU(s): RCCL ghost exchange + dot-product all-reduce" % world},
         "gmres_outer_iters_per_step": outer / max(1, len(stats)),
         "gmres_outer_iters_per_sec": outer / t_solve if t_solve > 0 else None,
         "inner_F_iters_per_step": sum(s["inner_F_iterations"] for s in stats) / max(1, len(stats)),
