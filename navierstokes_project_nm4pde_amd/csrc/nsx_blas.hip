@@ -75,11 +75,36 @@ __global__ __launch_bounds__(256) void k_reduce(int n, int split, int gap, doubl
                                                 const double *__restrict__ w, const double *__restrict__ scal,
                                                 const double *__restrict__ partial_in, double *__restrict__ partial) {
   __shared__ double sh[5];
-  double acc = 0.0;
-  const double alpha = OP == OP_ADD_AND_DOT ? sval(scal, partial_in, a, sh + 4) : 0.0;
+  constexpr int U = 4;
   const bool self = (w == d);
+  const int stride = gridDim.x * 256;
+  // first batch of loads is issued BEFORE the coefficient is known: the partial-sum prologue (an L2 round trip, a wave
+  // reduction and two barriers) then overlaps with the HBM latency of the stream instead of preceding it
+  double dv[U], vv[U], wv[U];
+  int idx[U];
+#pragma unroll
+  for (int k = 0; k < U; ++k) {
+    const int i0 = blockIdx.x * 256 + threadIdx.x + k * stride;
+    const bool ok = i0 < n;
+    const int i = ok ? i0 + (i0 >= split ? gap : 0) : 0;
+    idx[k] = ok ? i : -1;
+    dv[k] = ok ? d[i] : 0.0;
+    vv[k] = (ok && OP == OP_ADD_AND_DOT) ? v[i] : 0.0;
+    wv[k] = (ok && !self) ? w[i] : 0.0;
+  }
+  const double alpha = OP == OP_ADD_AND_DOT ? sval(scal, partial_in, a, sh + 4) : 0.0;
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < U; ++k) {
+    double di = dv[k];
+    if (OP == OP_ADD_AND_DOT) {
+      di += alpha * vv[k];
+      if (idx[k] >= 0) d[idx[k]] = di;
+    }
+    acc += di * (self ? di : wv[k]);
+  }
 #pragma unroll 4
-  for (int i0 = blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += gridDim.x * 256) {
+  for (int i0 = blockIdx.x * 256 + threadIdx.x + U * stride; i0 < n; i0 += stride) {
     const int i = i0 + (i0 >= split ? gap : 0);
     double di = d[i];
     if (OP == OP_ADD_AND_DOT) {

@@ -124,6 +124,16 @@ struct HaloPlan {
   int n_own = 0;                            // ghosts start at node n_own
 };
 
+// LDS-staged ("blocked") SpMV schedule on a CSR graph: rows are cut into chunks of R consecutive rows; per chunk the
+// sorted unique column list and, per entry, the 16-bit position of its column in that list.  A workgroup stages the
+// chunk's x entries in LDS once (each x entry is gathered once per chunk instead of once per non-zero).
+struct SpmvBlocked {
+  int R = 0, n_chunks = 0, max_ucols = 0;
+  DevBuf<int32_t> cptr, ucols;
+  DevBuf<uint16_t> lidx;
+  double ucols_total = 0;
+};
+
 struct ProfEntry {
   int64_t launches = 0;
   double bytes = 0;  // algorithmic bytes of one launch (last seen)
@@ -160,6 +170,7 @@ struct nsx_handle {
   std::vector<int32_t> cell_n2_h, cell_n1_h;
   // ---- graphs and values
   nsx::DevCsr gA, gG, gB, gS, gPM;
+  nsx::SpmvBlocked blkA;
   nsx::DevBuf<double> vS0, vMass, vStiff, vConv, vF, vG, vB, vPM, vSchur, luF, luS;
   nsx::DevBuf<int32_t> bt_of_g;            // for every G entry (i,k): position of (k,i) in the B graph
   nsx::GatherMap gmA, gmG, gmB, gmPM;

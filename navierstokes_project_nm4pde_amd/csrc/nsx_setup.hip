@@ -211,6 +211,33 @@ void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> 
   s.pk_dinv.alloc(g.n_rows);
 }
 
+void build_blocked(nsx_handle *h, const Csr &g, int R, SpmvBlocked &b) {
+  b.R = R;
+  b.n_chunks = (g.n_rows + R - 1) / R;
+  std::vector<int32_t> cptr((size_t)b.n_chunks + 1, 0), ucols, tmp;
+  std::vector<uint16_t> lidx(g.nnz());
+  b.max_ucols = 0;
+  for (int c = 0; c < b.n_chunks; ++c) {
+    const int r0 = c * R, r1 = std::min(g.n_rows, r0 + R);
+    tmp.assign(g.colind.begin() + g.rowptr[r0], g.colind.begin() + g.rowptr[r1]);
+    std::sort(tmp.begin(), tmp.end());
+    tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+    if (tmp.size() > 65535) NSX_THROW(NSX_ERR_UNSUPPORTED, "blocked SpMV: chunk touches more than 65535 columns");
+    for (int p = g.rowptr[r0]; p < g.rowptr[r1]; ++p)
+      lidx[p] = (uint16_t)(std::lower_bound(tmp.begin(), tmp.end(), g.colind[p]) - tmp.begin());
+    ucols.insert(ucols.end(), tmp.begin(), tmp.end());
+    cptr[c + 1] = (int32_t)ucols.size();
+    b.max_ucols = std::max<int>(b.max_ucols, (int)tmp.size());
+  }
+  b.ucols_total = (double)ucols.size();
+  b.cptr.upload(cptr, h->stream);
+  b.ucols.upload(ucols, h->stream);
+  b.lidx.upload(lidx, h->stream);
+  if (getenv("NSX_DEBUG"))
+    fprintf(stderr, "[nsx] blocked spmv: rows %d R %d chunks %d unique cols/chunk avg %.0f max %d (nnz/unique %.1f)\n", g.n_rows, R, b.n_chunks,
+            b.ucols_total / b.n_chunks, b.max_ucols, (double)g.nnz() / b.ucols_total);
+}
+
 void build_schur_graph(nsx_handle *h) {
   // structural product block(1,0) * block(0,1); block(0,1) has the transposed pattern of block(1,0), and block(1,0)
   // is stored for every local (owned + ghost) pressure row, so the product is formed from B and B^T alone
@@ -434,6 +461,7 @@ void setup_mesh(nsx_handle *h, int n_cells, int n_cells1, const double *cell_coo
   h->gPM.host = build_graph(n_cells, np1, c1, h->NP_loc, np1, c1, h->NP_loc);
   truncate_rows(h->gPM.host, h->NP);
   upload_csr(h, h->gA, true);
+  build_blocked(h, h->gA.host, 128, h->blkA);
   upload_csr(h, h->gG, false);
   upload_csr(h, h->gB, false);
   upload_csr(h, h->gPM, true);

@@ -135,6 +135,80 @@ __global__ __launch_bounds__(256) void k_spmv_csr(int n_rows, const int32_t *__r
   if (lane == 0) y[row] = acc;
 }
 
+// LDS-staged SpMV: y[i][c] = sum_j A[i,j] x[j][c] with the chunk's x entries gathered ONCE into LDS (SpmvBlocked).
+// The per-non-zero stream is 8 B value + 2 B local column; the 24-B gathers of the plain kernel (10 M per product,
+// bound by the per-CU address rate, not by bytes) become ~1.5 M staged gathers + LDS reads.
+template <int DIM, int W>
+__global__ __launch_bounds__(256) void k_spmv_blocked(int n_rows, int R, const int32_t *__restrict__ rp, const uint16_t *__restrict__ lidx,
+                                                      const double *__restrict__ av, const int32_t *__restrict__ cptr,
+                                                      const int32_t *__restrict__ ucols, const double *__restrict__ x,
+                                                      double *__restrict__ y) {
+  extern __shared__ double xs[];
+  __shared__ int rps[257];
+  const int chunk = blockIdx.x;
+  const int c0 = cptr[chunk], nu = cptr[chunk + 1] - c0;
+  const int r0 = chunk * R, r1 = min(n_rows, r0 + R);
+  for (int t = threadIdx.x; t <= r1 - r0; t += 256) rps[t] = rp[r0 + t];
+  for (int t = threadIdx.x; t < nu; t += 256) {
+    const double *xj = x + (size_t)ucols[c0 + t] * DIM;
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) xs[t * DIM + c] = xj[c];
+  }
+  __syncthreads();
+  constexpr int G = 256 / W, U = 4;  // rows in flight per pass, loads per lane kept in flight
+  const int grp = threadIdx.x / W, lane = threadIdx.x % W;
+  // software pipeline over the rows of this lane group: the loads of the next row are issued before the current row is
+  // reduced, so a wave always has 2*U value loads + 2*U index loads outstanding instead of one dependent chain per row
+  double a[U], na[U];
+  int l[U], nl[U];
+  int row = r0 + grp;
+  auto fetch = [&](int rw, double (&va)[U], int (&vl)[U]) {
+    const bool live = rw < r1;
+    const int p0 = live ? rps[rw - r0] + lane : 0, e = live ? rps[rw - r0 + 1] : 0;
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int q = p0 + k * W;
+      const bool ok = q < e;
+      va[k] = ok ? av[q] : 0.0;
+      vl[k] = ok ? (int)lidx[q] : 0;
+    }
+  };
+  auto consume = [&](int rw, const double (&va)[U], const int (&vl)[U]) {
+    if (rw >= r1) return;
+    double acc[DIM];
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) acc[c] = 0.0;
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const double *xj = xs + vl[k] * DIM;
+#pragma unroll
+      for (int c = 0; c < DIM; ++c) acc[c] += va[k] * xj[c];
+    }
+    const int e = rps[rw - r0 + 1];
+    for (int p = rps[rw - r0] + lane + U * W; p < e; p += W) {  // rows longer than U*W entries (rare)
+      const double av_ = av[p];
+      const double *xj = xs + (int)lidx[p] * DIM;
+#pragma unroll
+      for (int c = 0; c < DIM; ++c) acc[c] += av_ * xj[c];
+    }
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) acc[c] = group_sum<W>(acc[c]);
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < DIM; ++c) y[(size_t)rw * DIM + c] = acc[c];
+    }
+  };
+  // two register sets, no moves: while one row is reduced the loads of the next two are in flight
+  fetch(row, a, l);
+  fetch(row + G, na, nl);
+  for (; row < r1; row += 2 * G) {
+    consume(row, a, l);
+    fetch(row + 2 * G, a, l);
+    consume(row + G, na, nl);
+    fetch(row + 3 * G, na, nl);
+  }
+}
+
 static double bytes_vel(nsx_handle *h, bool with_g) {
   double b = 12.0 * h->gA.nnz() + (double)h->N2 * (4 + 8.0 * h->dim * 2);
   if (with_g) b += (4.0 + 8.0 * h->dim) * h->gG.nnz() + 4.0 * h->N2 + 8.0 * h->NP;
@@ -144,6 +218,20 @@ static double bytes_vel(nsx_handle *h, bool with_g) {
 void spmv_F(nsx_handle *h, const double *vals, const double *x, double *y) {
   comm_halo_u(h, x);
   LaunchScope ls(h, "spmv_F", bytes_vel(h, false));
+  static const bool blocked = !(getenv("NSX_SPMV_BLOCKED") && atoi(getenv("NSX_SPMV_BLOCKED")) == 0);
+  if (blocked && h->blkA.n_chunks > 0) {
+    const SpmvBlocked &b = h->blkA;
+    const size_t shm = (size_t)b.max_ucols * h->dim * sizeof(double);
+    if (shm <= 64 * 1024) {
+      if (h->dim == 2)
+        hipLaunchKernelGGL((k_spmv_blocked<2, 16>), dim3(b.n_chunks), dim3(256), shm, h->stream, h->N2, b.R, h->gA.rowptr.p, b.lidx.p, vals,
+                           b.cptr.p, b.ucols.p, x, y);
+      else
+        hipLaunchKernelGGL((k_spmv_blocked<3, 16>), dim3(b.n_chunks), dim3(256), shm, h->stream, h->N2, b.R, h->gA.rowptr.p, b.lidx.p, vals,
+                           b.cptr.p, b.ucols.p, x, y);
+      return;
+    }
+  }
   static const int Wsel = getenv("NSX_SPMV_W") ? atoi(getenv("NSX_SPMV_W")) : 16;
 #define NSX_SPMV(D, W_)                                                                                                          \
   hipLaunchKernelGGL((k_spmv_vel<D, W_, false>), dim3((cdiv((int64_t)h->N2 * W_, 256) + 7) & ~7), dim3(256), 0, h->stream, h->N2, \
