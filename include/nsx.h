@@ -155,6 +155,18 @@ int nsx_scalar_graph_nnz(nsx_handle *h, int which, int64_t *nnz); /* which: 0 ve
 int nsx_scalar_graph(nsx_handle *h, int which, int32_t *rowptr, int32_t *colind);
 int nsx_ilu_get(nsx_handle *h, int which, double *values);
 
+/* ---- forces on the obstacle ---- */
+/* NavierStokes::compute_forces (reference NavierStokes3D.cpp:744-846, NavierStokes2D.cpp:752-859): drag and lift by
+ * face quadrature over the faces with boundary id 3.  cells[f] = position of the face's cell in the cell list given to
+ * nsx_set_mesh(_distributed), local_faces[f] = deal.II face number inside that cell.  Face tables: for every face of the
+ * reference cell the shape values / reference gradients at its n_qf quadrature points, N2f[(face*n_qf+q)][n_p2] etc.,
+ * weights wf[n_qf] summing to 1 (QGaussSimplex<dim-1>(3) in 3D, QGauss<1>(3) in 2D).  Returns the raw forces; the
+ * coefficients 2F/(rho U^2 D H) (3D) and 2F/(U^2 D) (2D) are host arithmetic (NavierStokes3D.cpp:835-842).
+ * In a multi-process run each rank passes the faces of the cells it owns and the sum is all-reduced. */
+int nsx_set_force_faces(nsx_handle *h, int n_faces, const int32_t *cells, const int32_t *local_faces, int n_qf, const double *N2f,
+                        const double *dN2f, const double *N1f, const double *wf);
+int nsx_compute_forces(nsx_handle *h, double *drag, double *lift);
+
 /* ---- measurement ---- */
 /* Per-kernel HIP-event timing of the hot path (bench.py roofline): enable, run, then read name/count/total-ms. */
 int nsx_profile_enable(nsx_handle *h, int on);

@@ -194,6 +194,10 @@ struct nsx_handle {
   nsx::DevBuf<double> scal;                 // device scalars
   int slot_nb[nsx::N_SLOTS] = {0};          // >0: the slot's value is still spread over that many partial sums
   double *scal_host = nullptr;              // pinned mirror
+  // ---- force evaluation (compute_forces): obstacle faces + face-quadrature tables
+  int ff_n = 0, ff_nq = 0;
+  nsx::DevBuf<int32_t> ff_cells, ff_lf;
+  nsx::DevBuf<double> ff_N2, ff_dN2, ff_N1, ff_w, ff_out;
   // ---- profiling
   bool prof_on = false;
   std::map<std::string, nsx::ProfEntry> prof;

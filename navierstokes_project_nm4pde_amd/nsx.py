@@ -23,7 +23,7 @@ API = [
     "nsx_solve_time_step", "nsx_prec_initialize", "nsx_prec_vmult", "nsx_system_vmult", "nsx_ilu_apply",
     "nsx_export_block", "nsx_schur_nnz", "nsx_schur_get", "nsx_scalar_graph_nnz", "nsx_scalar_graph", "nsx_ilu_get",
     "nsx_profile_enable", "nsx_profile_reset", "nsx_profile_count", "nsx_profile_get", "nsx_comm_unique_id",
-    "nsx_comm_init", "nsx_comm_init_callbacks", "nsx_set_mesh_distributed",
+    "nsx_comm_init", "nsx_comm_init_callbacks", "nsx_set_mesh_distributed", "nsx_set_force_faces", "nsx_compute_forces",
 ]
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _f64p, C.c_int)
@@ -90,6 +90,8 @@ def lib():
     L.nsx_comm_init_callbacks.argtypes = [vp, C.c_int, C.c_int, ALLREDUCE_FN, EXCHANGE_FN, C.c_void_p]
     L.nsx_set_mesh_distributed.argtypes = [vp, C.c_int, C.c_int, C.c_int, _i32p, _f64p, C.c_int, C.c_int, C.c_int, C.c_int,
                                            _i32p, _i32p, C.c_int, _i32p, _i32p, _i32p, _i32p, _i32p]
+    L.nsx_set_force_faces.argtypes = [vp, C.c_int, _i32p, _i32p, C.c_int, _f64p, _f64p, _f64p, _f64p]
+    L.nsx_compute_forces.argtypes = [vp, _f64p, _f64p]
     L._nsx_ready = True
     return L
 
@@ -294,6 +296,25 @@ class Nsx:
         dst = np.empty_like(src)
         self._ck(self.L.nsx_ilu_apply(self._h, which, _d(dst), _d(src)))
         return dst
+
+    # -- forces --------------------------------------------------------------------------------
+    def set_force_faces(self, cells, lfaces, ftab):
+        """obstacle faces as (global cell id, local face); in a multi-process run only the faces of owned cells are kept."""
+        cells, lfaces = np.asarray(cells), np.asarray(lfaces)
+        if self.world > 1:
+            n_sub = self.dofs.n_subdomains // self.world
+            mine = (self.dofs.mesh.subdomain[cells] // n_sub) == self.rank
+            pos = {int(c): i for i, c in enumerate(self.view["cell_ids"])}
+            cells = np.array([pos[int(c)] for c in cells[mine]], dtype=np.int32)
+            lfaces = lfaces[mine]
+        cells, lfaces = _ci(cells), _ci(lfaces)
+        N2, dN2, N1, w = _cd(ftab.N2), _cd(ftab.dN2), _cd(ftab.N1), _cd(ftab.weights[:ftab.n_qf])
+        self._ck(self.L.nsx_set_force_faces(self._h, len(cells), _i(cells), _i(lfaces), ftab.n_qf, _d(N2), _d(dN2), _d(N1), _d(w)))
+
+    def compute_forces(self):
+        d, l = C.c_double(), C.c_double()
+        self._ck(self.L.nsx_compute_forces(self._h, C.byref(d), C.byref(l)))
+        return d.value, l.value
 
     # -- export --------------------------------------------------------------------------------
     def export_block(self, which, block, graph=None):

@@ -239,3 +239,44 @@ def run_convergence_case(backend_factory, n, prec=0, tol_abs=1e-4, inner_rtol=1e
     ex.set_time(T)
     return {"h": 1.0 / (n / 2.0) / 1.0, "L2": velocity_error(mesh, dofs, sol, ex, htab, "L2"),
             "H1": velocity_error(mesh, dofs, sol, ex, htab, "H1"), "stats": stats, "n_dofs": dofs.n_dofs, "solution": sol}
+
+
+# ------------------------------------------------------------------ forces on the obstacle
+def obstacle_faces(mesh, boundary_id=3):
+    """(cell, deal.II local face number) of every boundary face with `boundary_id` (the loop NavierStokes3D.cpp:771-786)."""
+    faces = _TET_FACES if mesh.dim == 3 else _TRI_FACES
+    sel = np.nonzero(mesh.bface_ids == boundary_id)[0]
+    cells = mesh.bface_cells[sel].astype(np.int32)
+    lf = np.empty(len(sel), dtype=np.int32)
+    for k, bf in enumerate(sel):
+        cv = mesh.cells[cells[k]]
+        fset = set(mesh.bfaces[bf].tolist())
+        lf[k] = next(i for i, fv in enumerate(faces) if {int(cv[j]) for j in fv} == fset)
+    return cells, lf
+
+
+def force_coefficients(dim, drag, lift, mean_v, rho=1.0, D=0.1, H=0.41):
+    """c_D, c_L: 2F/(rho U^2 D H) in 3D (NavierStokes3D.cpp:835-842), 2F/(U^2 D) in 2D (NavierStokes2D.cpp:849-853)."""
+    den = rho * mean_v * mean_v * D * H if dim == 3 else mean_v * mean_v * D
+    return 2.0 * drag / den, 2.0 * lift / den
+
+
+def pressure_difference(mesh, dofs, solution, p_a=None, p_e=None):
+    """compute_pressure_difference (NavierStokes3D.cpp:849-923): P1 pressure at two points, p(A) - p(E)."""
+    dim = mesh.dim
+    p_a = np.array(p_a if p_a is not None else ([0.45, 0.2, 0.205] if dim == 3 else [0.15, 0.2]))
+    p_e = np.array(p_e if p_e is not None else ([0.55, 0.2, 0.205] if dim == 3 else [0.25, 0.2]))
+    X = mesh.vertices[mesh.cells]
+    J = np.transpose(X[:, 1:] - X[:, :1], (0, 2, 1))
+    Jinv = np.linalg.inv(J)
+
+    def value(pt):
+        xi = np.einsum("ckd,cd->ck", Jinv, pt[None, :] - X[:, 0])
+        lam = np.c_[1 - xi.sum(1), xi]
+        c = int(np.argmax(lam.min(1)))                   # cell containing the point (largest minimal barycentric)
+        if lam[c].min() < -1e-10:
+            raise ValueError("point %s is outside the mesh" % pt)
+        pd = dofs.cell_dofs[c][[(dim + 1) * v + dim for v in range(dim + 1)]]
+        return float(lam[c] @ solution[pd])
+
+    return value(p_a) - value(p_e)

@@ -59,6 +59,7 @@ def lib():
         L.orc_ilu_F.argtypes = [vp]
         L.orc_ilu_S.restype = _f64p
         L.orc_ilu_S.argtypes = [vp]
+        L.orc_compute_forces.argtypes = [vp, C.c_int, _i32p, _i32p, C.c_int, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p]
         L.orc_spmv.argtypes = [C.c_int, _i32p, _i32p, _f64p, _f64p, _f64p]
         L.orc_system_vmult.argtypes = [vp, _f64p, _f64p]
         L.orc_ilu0_factor.argtypes = [C.c_int, _i32p, _i32p, _f64p, C.c_int, _i32p, _f64p]
@@ -174,6 +175,14 @@ class Oracle:
         st = Stats()
         self.L.orc_prec_vmult(self._h, prec, inner_rtol, inner_maxiter, _d(dst), _d(src), C.byref(st))
         return dst, st.as_dict()
+
+    def compute_forces(self, cells, lfaces, ftab):
+        cells, lfaces = _ci(cells), _ci(lfaces)
+        N2, dN2, N1, w = _cd(ftab.N2), _cd(ftab.dN2), _cd(ftab.N1), _cd(ftab.weights[:ftab.n_qf])
+        d, l = C.c_double(), C.c_double()
+        self.L.orc_compute_forces(self._h, len(cells), _i(cells), _i(lfaces), ftab.n_qf, _d(N2), _d(dN2), _d(N1), _d(w),
+                                  C.byref(d), C.byref(l))
+        return d.value, l.value
 
     def system_vmult(self, src):
         src = _cd(src)

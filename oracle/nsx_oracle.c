@@ -1038,3 +1038,100 @@ void orc_solve_time_step(orc *o, int type, double tol_abs, double inner_rtol, in
   if (r.status && st->status == 0) st->status = 1;
   v_copy(n, o->sol, o->sol_owned); /* solution = solution_owned  (NS3D:638) */
 }
+
+/* NavierStokes::compute_forces (NS3D:744-846 / NS2D:752-859): face loop over boundary id 3 with FEFaceValues.
+ * Faces are given as (cell, deal.II local face); face tables as in nsxh_tables rule 1 (weights sum to 1 per face).
+ * The geometry (outward normal, face measure) is computed here from the vertex coordinates (cross products), i.e.
+ * independently of the J^{-T} n_ref formula the device kernel uses. */
+void orc_compute_forces(orc *o, int n_faces, const int32_t *cells, const int32_t *lfaces, int n_qf, const double *N2f,
+                        const double *dN2f, const double *N1f, const double *wf, double *drag_out, double *lift_out) {
+  const int dim = o->dim, nv = dim + 1, np2 = o->np2, np1 = o->np1;
+  static const int TETF[4][3] = {{0, 1, 2}, {1, 0, 3}, {0, 2, 3}, {2, 1, 3}};
+  static const int TRIF[3][2] = {{0, 1}, {1, 2}, {2, 0}};
+  const double rho = 1.0, nu = o->nu;
+  double local_drag = 0.0, local_lift = 0.0;
+  for (int f = 0; f < n_faces; ++f) {
+    const int cell = cells[f], lf = lfaces[f];
+    const double *X = o->cell_coords + (size_t)cell * nv * dim;
+    const int32_t *dofs = o->cell_dofs + (size_t)cell * o->dpc;
+    double J[3][3] = {{0}}, Ji[3][3] = {{0}}, det;
+    for (int d = 0; d < dim; ++d)
+      for (int k = 0; k < dim; ++k) J[d][k] = X[(k + 1) * dim + d] - X[d];
+    if (dim == 2) {
+      det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+      Ji[0][0] = J[1][1] / det; Ji[0][1] = -J[0][1] / det; Ji[1][0] = -J[1][0] / det; Ji[1][1] = J[0][0] / det;
+    } else {
+      det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) - J[0][1] * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) +
+            J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+      Ji[0][0] = (J[1][1] * J[2][2] - J[1][2] * J[2][1]) / det; Ji[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) / det;
+      Ji[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) / det; Ji[1][0] = (J[1][2] * J[2][0] - J[1][0] * J[2][2]) / det;
+      Ji[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) / det; Ji[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) / det;
+      Ji[2][0] = (J[1][0] * J[2][1] - J[1][1] * J[2][0]) / det; Ji[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) / det;
+      Ji[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) / det;
+    }
+    /* outward unit normal and measure of the face from its vertices */
+    double nrm[3] = {0, 0, 0}, meas, opp[3] = {0, 0, 0};
+    int opp_v = 0;
+    if (dim == 3) {
+      const double *a = X + 3 * TETF[lf][0], *b = X + 3 * TETF[lf][1], *c = X + 3 * TETF[lf][2];
+      const double e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, e2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+      nrm[0] = e1[1] * e2[2] - e1[2] * e2[1]; nrm[1] = e1[2] * e2[0] - e1[0] * e2[2]; nrm[2] = e1[0] * e2[1] - e1[1] * e2[0];
+      const double l = sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+      meas = 0.5 * l;
+      for (int d = 0; d < 3; ++d) nrm[d] /= l;
+      opp_v = 6 - TETF[lf][0] - TETF[lf][1] - TETF[lf][2];
+      for (int d = 0; d < 3; ++d) opp[d] = X[3 * opp_v + d] - a[d];
+    } else {
+      const double *a = X + 2 * TRIF[lf][0], *b = X + 2 * TRIF[lf][1];
+      const double e[2] = {b[0] - a[0], b[1] - a[1]};
+      meas = sqrt(e[0] * e[0] + e[1] * e[1]);
+      nrm[0] = e[1] / meas; nrm[1] = -e[0] / meas;
+      opp_v = 3 - TRIF[lf][0] - TRIF[lf][1];
+      for (int d = 0; d < 2; ++d) opp[d] = X[2 * opp_v + d] - a[d];
+    }
+    double s = 0;
+    for (int d = 0; d < dim; ++d) s += nrm[d] * opp[d];
+    if (s > 0) for (int d = 0; d < dim; ++d) nrm[d] = -nrm[d]; /* outward = away from the opposite vertex */
+    for (int q = 0; q < n_qf; ++q) {
+      const int tq = lf * n_qf + q;
+      const double JxW = wf[q] * meas;
+      /* get_function_values(pressure) / get_function_gradients(velocity) on the face (NS3D:795-796) */
+      double p = 0.0, G[3][3] = {{0}};
+      for (int i = 0; i < o->dpc; ++i) {
+        const int c = o->l_comp[i], a = o->l_node[i];
+        const double ui = o->sol[dofs[i]];
+        if (c == dim) {
+          p += ui * N1f[tq * np1 + a];
+        } else {
+          for (int d = 0; d < dim; ++d) {
+            double g = 0;
+            for (int k = 0; k < dim; ++k) g += Ji[k][d] * dN2f[(tq * np2 + a) * dim + k];
+            G[c][d] += ui * g;
+          }
+        }
+      }
+      double n[3] = {-nrm[0], -nrm[1], -nrm[2]}; /* n = -fe_face_values.normal_vector(q) */
+      if (dim == 3) { /* NS3D:799-826 */
+        const double nx = n[0], ny = n[1];
+        const double tangent[3] = {ny, -nx, 0.};
+        const double t2 = tangent[0] * tangent[0] + tangent[1] * tangent[1] + tangent[2] * tangent[2];
+        double ngt = 0;
+        for (int i = 0; i < 3; ++i)
+          for (int j = 0; j < 3; ++j) ngt += n[i] * G[i][j] * (tangent[j] / t2);
+        local_drag += (rho * nu * ngt * ny - p * nx) * JxW;
+        local_lift -= (rho * nu * ngt * nx + p * ny) * JxW;
+      } else { /* NS2D:821-838 */
+        double forces[2];
+        for (int i = 0; i < 2; ++i) {
+          double v = 0;
+          for (int j = 0; j < 2; ++j) v += (nu * G[i][j] - (i == j ? p : 0.0)) * n[j];
+          forces[i] = v * JxW;
+        }
+        local_drag += forces[0];
+        local_lift += forces[1];
+      }
+    }
+  }
+  *drag_out = local_drag;
+  *lift_out = local_lift;
+}

@@ -75,6 +75,10 @@ int orc_schur(orc *, const int32_t **rowptr, const int32_t **colind, const doubl
 const double *orc_ilu_F(orc *);
 const double *orc_ilu_S(orc *);
 
+/* NavierStokes::compute_forces (NS3D:744-846 / NS2D:752-859) on the ghosted `solution`: raw drag and lift. */
+void orc_compute_forces(orc *, int n_faces, const int32_t *cells, const int32_t *lfaces, int n_qf, const double *N2f,
+                        const double *dN2f, const double *N1f, const double *wf, double *drag, double *lift);
+
 /* ---- stand-alone kernels (unit parity tests) ---- */
 void orc_spmv(int n_rows, const int32_t *rowptr, const int32_t *colind, const double *vals, const double *x, double *y);
 void orc_system_vmult(orc *, double *dst, const double *src);

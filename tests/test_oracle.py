@@ -290,3 +290,26 @@ def test_ethier_steinmann_convergence_rates():
     # (~4e-4 * |u.grad u|), a floor the L2 error approaches on the finest mesh: the rate bends from 2.9 to 2.6
     assert rate_l2[0] > 2.8 and rate_l2[1] > 2.5 and min(rate_h1) > 1.85, (l2, h1)
     assert l2[-1] < 6e-3 and h1[-1] < 0.15
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_forces_hydrostatic_known_answer(dim):
+    """compute_forces on u = 0, p = x: drag = -int p n_x dS over the obstacle with n pointing into the fluid = -|obstacle|
+    (divergence theorem on the polygonal cylinder), lift = 0."""
+    from navierstokes_project_nm4pde_amd.problem import obstacle_faces
+    p = Problem("cylinder", dim, 2)
+    d, o = p.dofs, p.oracle()
+    o.solution[:] = 0.0
+    o.solution[d.n_u:] = d.support_points[d.n_u:, 0]
+    cells, lf = obstacle_faces(p.mesh)
+    ftab = Tables(dim, Tables.FACE)
+    drag, lift = o.compute_forces(cells, lf, ftab)
+    Xm = p.mesh.vertices[p.mesh.cells]
+    fluid = abs(np.linalg.det(Xm[:, 1:] - Xm[:, :1])).sum() / (2 if dim == 2 else 6)
+    box = 2.2 * 0.41 if dim == 2 else 2.5 * 0.41 * 0.41
+    assert abs(drag + (box - fluid)) < 1e-12 and abs(lift) < 1e-12
+    # a rigid shear u = (y, 0, 0): grad u = e_x (x) e_y, so the 2D stress force is nu * int n_y dS e_x = 0 on a closed curve
+    o.solution[:] = 0.0
+    o.solution[0:d.n_u:dim] = d.support_points[0:d.n_u:dim, 1]
+    drag, lift = o.compute_forces(cells, lf, ftab)
+    assert abs(drag) < 1e-12 and abs(lift) < 1e-12
