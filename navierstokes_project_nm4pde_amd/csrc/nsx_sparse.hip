@@ -651,7 +651,8 @@ void ilu_solve(nsx_handle *h, const DevCsr &g, const IluSchedule &s, const doubl
 #define NSX_PK(NC)                                              \
     if (lw == 8) return launch_packed<NC, 8>(h, s, b, x);       \
     if (lw == 16) return launch_packed<NC, 16>(h, s, b, x);     \
-    if (lw == 32) return launch_packed<NC, 32>(h, s, b, x);
+    if (lw == 32) return launch_packed<NC, 32>(h, s, b, x);       \
+    if (lw == 64) return launch_packed<NC, 64>(h, s, b, x);
     if (ncomp == 1) { NSX_PK(1) }
     if (ncomp == 2) { NSX_PK(2) }
     if (ncomp == 3) { NSX_PK(3) }

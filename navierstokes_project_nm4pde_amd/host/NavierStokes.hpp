@@ -107,6 +107,7 @@ public:
     nsxh_tables_free(t);
     ck(nsx_set_mesh(h, nsxh_mesh_n_cells(mesh), nsxh_dofs_per_cell(dofs), nsxh_cell_dofs(dofs), nsxh_cell_coords(dofs), n_u, n_p));
     if (n_ranks > 1) ck(nsx_set_ranks(h, nsxh_n_subdomains(dofs), nsxh_owned_u_ptr(dofs), nsxh_owned_p_ptr(dofs)));
+    setup_force_faces();
   }
 
   void solve() {  // NavierStokes3D.cpp:687-741
@@ -123,8 +124,34 @@ public:
       if (time == deltat) assemble(time);
       else assemble_time_step(time);
       solve_time_step();
+      // NavierStokes3D.cpp:728-733 (forces only after t = 0.1); NavierStokes2D.cpp:737-741 (every step)
+      if (dim == 2 || time > 0.1) {
+        const std::vector<double> coefficients = compute_forces();
+        c_D_max = std::max(coefficients[0], c_D_max);
+        c_L_min = std::min(coefficients[1], c_L_min);
+      }
     }
+    out() << "===============================================" << std::endl
+          << "Drag Coefficient Max ----->   " << c_D_max << std::endl
+          << std::endl
+          << "Lift Coefficient Min ----->   " << c_L_min << std::endl
+          << "===============================================" << std::endl;
   }
+
+  // NavierStokes::compute_forces (NavierStokes3D.cpp:744-846 / NavierStokes2D.cpp:752-859)
+  std::vector<double> compute_forces() {
+    out() << "===============================================" << std::endl << "Computing forces: " << std::endl;
+    double drag = 0, lift = 0;
+    ck(nsx_compute_forces(h, &drag, &lift));
+    out() << "Drag :\t " << drag << " Lift :\t " << lift << std::endl;
+    const double mean_v = inlet_velocity.getMeanVelocity();
+    const double D = 0.1, H = 0.41, rho = 1.;
+    const double den = dim == 3 ? rho * mean_v * mean_v * D * H : mean_v * mean_v * D;
+    const double c_d = (2. * drag) / den, c_l = (2. * lift) / den;
+    out() << "Coeff:\t " << c_d << " Coeff:\t " << c_l << std::endl;
+    return {c_d, c_l};
+  }
+  double c_D_max = -999, c_L_min = 999;
 
   std::vector<double> get_solution() const {
     std::vector<double> x((size_t)n_u + n_p);
@@ -176,6 +203,35 @@ protected:
     time_solve.push_back(st.t_solve);
     gmres_iterations.push_back(st.outer_iterations);
     out() << "Result:  " << st.outer_iterations << " GMRES iterations" << std::endl;
+  }
+
+  void setup_force_faces() {  // faces with boundary id 3 and the face-quadrature tables (FEFaceValues of compute_forces)
+    static const int TETF[4][3] = {{0, 1, 2}, {1, 0, 3}, {0, 2, 3}, {2, 1, 3}};
+    static const int TRIF[3][2] = {{0, 1}, {1, 2}, {2, 0}};
+    const int nbf = nsxh_mesh_n_bfaces(mesh);
+    const int32_t *bf = nsxh_mesh_bfaces(mesh), *ids = nsxh_mesh_bface_ids(mesh), *bc = nsxh_mesh_bface_cells(mesh);
+    const int32_t *cells = nsxh_mesh_cells(mesh);
+    std::vector<int32_t> fc, fl;
+    for (int f = 0; f < nbf; ++f) {
+      if (ids[f] != 3) continue;
+      const int32_t *cv = cells + (size_t)bc[f] * (dim + 1);
+      for (int lf = 0; lf <= dim; ++lf) {
+        int match = 0;
+        for (int k = 0; k < dim; ++k) {
+          const int32_t v = cv[dim == 3 ? TETF[lf][k] : TRIF[lf][k]];
+          for (int q = 0; q < dim; ++q) match += v == bf[(size_t)f * dim + q];
+        }
+        if (match == dim) {
+          fc.push_back(bc[f]);
+          fl.push_back(lf);
+          break;
+        }
+      }
+    }
+    nsxh_tables *t = nsxh_tables_create(dim, 1, 0);
+    ck(nsx_set_force_faces(h, (int)fc.size(), fc.data(), fl.data(), nsxh_tables_n_qf(t), nsxh_tables_N2(t), nsxh_tables_dN2(t),
+                           nsxh_tables_N1(t), nsxh_tables_weights(t)));
+    nsxh_tables_free(t);
   }
 
   void ck(int rc) const {
