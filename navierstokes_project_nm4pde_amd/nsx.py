@@ -187,6 +187,12 @@ class Nsx:
             ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
             self._ck(L.nsx_comm_init(self._h, rank, world, ident))
 
+    def comm_init_single(self):
+        """1-rank RCCL communicator on this handle: every dot product then goes through ncclAllReduce (API self-test)."""
+        ident = (C.c_uint8 * 128)()
+        self._ck(self.L.nsx_comm_unique_id(ident))
+        self._ck(self.L.nsx_comm_init(self._h, 0, 1, ident))
+
     def gather_solution(self):
         """Global solution vector on every rank (owned parts summed over the process group)."""
         x = np.zeros(self.n)
