@@ -129,6 +129,27 @@ __global__ __launch_bounds__(256) void k_finalize(int slot0, NbArgs nbs, const d
   if (threadIdx.x == 0) scal[slot] = v;
 }
 
+// finalise a range of slots AND publish them to mapped host memory; the block that finishes last raises the flag
+__global__ __launch_bounds__(256) void k_publish(int slot0, int count, NbArgs nbs, const double *__restrict__ partial,
+                                                 double *__restrict__ scal, double *pub_vals, unsigned long long *pub_flag,
+                                                 unsigned long long seq, unsigned int *counter) {
+  __shared__ double sh;
+  const int slot = slot0 + blockIdx.x;
+  const int nb = nbs.nb[blockIdx.x];
+  const double v = slot_value(scal, partial, slot, nb, &sh);
+  if (threadIdx.x == 0) {
+    if (nb) scal[slot] = v;
+    __hip_atomic_store(pub_vals + slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    const unsigned int ticket = atomicAdd(counter, 1u);
+    if (ticket == (unsigned int)count - 1) {
+      *counter = 0;
+      __threadfence_system();
+      __hip_atomic_store(pub_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 static int red_blocks(int n) { return std::max(1, std::min(RED_BLOCKS, cdiv(n, 1024))); }
 
 static SRef sref(nsx_handle *h, double c, int num, int den) {
@@ -284,10 +305,27 @@ double read_scalar(nsx_handle *h, int slot) {
   return v;
 }
 void read_scalars(nsx_handle *h, int slot0, int count, double *out) {
-  finalize_slots(h, slot0, count);
-  HIP_CHECK(hipMemcpyAsync(h->scal_host + slot0, h->scal.p + slot0, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_CHECK(hipStreamSynchronize(h->stream));
-  for (int i = 0; i < count; ++i) out[i] = h->scal_host[slot0 + i];
+  if (count > 64) NSX_THROW(NSX_ERR_ARG, "internal: read_scalars range too long");
+  NbArgs args;
+  for (int i = 0; i < count; ++i) {
+    args.nb[i] = h->slot_nb[slot0 + i];
+    h->slot_nb[slot0 + i] = 0;
+  }
+  const unsigned long long seq = ++h->pub_seq;
+  unsigned long long *flag_dev = (unsigned long long *)(h->pub_dev + N_SLOTS);
+  volatile unsigned long long *flag_host = (volatile unsigned long long *)(h->pub_host + N_SLOTS);
+  hipLaunchKernelGGL(k_publish, dim3(count), dim3(256), 0, h->stream, slot0, count, args, h->red_partial.p, h->scal.p, h->pub_dev, flag_dev, seq,
+                     h->pub_counter.p);
+  // poll the sequence number (bounded: fall back to a stream synchronisation, which also surfaces launch errors)
+  unsigned long long spins = 0;
+  while (__atomic_load_n(flag_host, __ATOMIC_ACQUIRE) != seq) {
+    if (++spins > 200000000ull) {
+      HIP_CHECK(hipStreamSynchronize(h->stream));
+      if (__atomic_load_n(flag_host, __ATOMIC_ACQUIRE) != seq) NSX_THROW(NSX_ERR_HIP, "scalar publication never arrived");
+      break;
+    }
+  }
+  for (int i = 0; i < count; ++i) out[i] = h->pub_host[slot0 + i];
 }
 void write_scalar(nsx_handle *h, int slot, double v) {
   HIP_CHECK(hipStreamSynchronize(h->stream));

@@ -194,6 +194,11 @@ struct nsx_handle {
   nsx::DevBuf<double> scal;                 // device scalars
   int slot_nb[nsx::N_SLOTS] = {0};          // >0: the slot's value is still spread over that many partial sums
   double *scal_host = nullptr;              // pinned mirror
+  // host-visible publication of scalars without a memcpy + stream sync: the publishing kernel writes the values and then
+  // a sequence number into fine-grained mapped host memory, the host polls the sequence number
+  double *pub_host = nullptr, *pub_dev = nullptr;  // [N_SLOTS] values, then the flag word
+  unsigned long long pub_seq = 0;
+  nsx::DevBuf<unsigned int> pub_counter;
   // ---- force evaluation (compute_forces): obstacle faces + face-quadrature tables
   int ff_n = 0, ff_nq = 0;
   nsx::DevBuf<int32_t> ff_cells, ff_lf;

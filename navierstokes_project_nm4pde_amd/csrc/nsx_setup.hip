@@ -338,6 +338,11 @@ int nsx_create(const nsx_params *p, nsx_handle **out) {
     h->scal.zero(h->stream);
     h->red_partial.alloc((size_t)N_SLOTS * 1024);
     HIP_CHECK(hipHostMalloc((void **)&h->scal_host, N_SLOTS * sizeof(double), hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc((void **)&h->pub_host, (N_SLOTS + 8) * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+    memset(h->pub_host, 0, (N_SLOTS + 8) * sizeof(double));
+    HIP_CHECK(hipHostGetDevicePointer((void **)&h->pub_dev, h->pub_host, 0));
+    h->pub_counter.alloc(1);
+    h->pub_counter.zero(h->stream);
   } catch (const nsx::Error &e) {
     g_create_error = e.msg;
     delete h;
@@ -359,6 +364,7 @@ int nsx_destroy(nsx_handle *h) {
     }
   for (auto *b : h->pool) delete b;
   if (h->scal_host) (void)hipHostFree(h->scal_host);
+  if (h->pub_host) (void)hipHostFree(h->pub_host);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return NSX_OK;
