@@ -105,6 +105,7 @@ struct IluSchedule {
   // packed wave-per-block solve stream: slabs of 64 slots {value, meta}; meta = col | last_of_step<<15 | (dst_row+1)<<16
   int lanes_per_row = 8;
   int64_t n_slabs = 0;
+  int prio_slabs = 1 << 30;      // blocks with more slabs than this run at raised wave priority
   bool packed_ok = false;
   DevBuf<int32_t> pk_slab_ptr;  // [2*n_blocks+1]: forward slabs, then backward slabs, per block
   DevBuf<int32_t> pk_meta;      // [n_slabs*64]

@@ -174,7 +174,7 @@ void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> 
                 m |= (g.colind[q] - r0);
                 slot_of[q] = (int32_t)(base + lane);
               }
-              if (k == K - 1 && l == 0) m |= (work[w0 + gi] - r0 + 1) << 16;
+              if (k == K - 1 && l < 4) m |= (work[w0 + gi] - r0 + 1) << 16;  // lanes 0..3 of the group: one per component
             }
             meta[base + lane] = m;
           }
@@ -189,6 +189,12 @@ void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> 
     slab_ptr[2 * (size_t)b + 2] = (int32_t)(meta.size() / 64);
   }
   s.n_slabs = (int64_t)meta.size() / 64;
+  {
+    int64_t mx = 0;
+    for (int b = 0; b < nb; ++b) mx = std::max<int64_t>(mx, slab_ptr[2 * b + 2] - slab_ptr[2 * b]);
+    const double frac = getenv("NSX_PRIO_FRAC") ? atof(getenv("NSX_PRIO_FRAC")) : 0.5;
+    s.prio_slabs = (int)(frac * (double)mx);
+  }
   if (getenv("NSX_DEBUG")) {
     int64_t max_slabs = 0, steps = 0, max_steps = 0, used = 0;
     for (int b = 0; b < nb; ++b) {

@@ -547,19 +547,52 @@ __global__ __launch_bounds__(256) void k_ilu_solve(const int32_t *__restrict__ b
 // stream of 64-slot slabs {value, meta} laid out at setup in exactly the order the wave consumes it (nsx_setup.hip),
 // so the only dependent chain per step is LDS gather -> FMA -> LW-lane DPP reduction -> LDS update; the global loads
 // are address-independent of x and are prefetched PF slabs ahead in registers.
+// Step end: sum the NCOMP partial sums over the LW lanes of each row group and update x.  After the two quad stages the
+// four lanes of a quad hold identical sums, so lane q of every quad keeps component q and the remaining stages run on
+// ONE register instead of NCOMP; they use row rotations by 4 and 8 (which preserve the position inside a quad, unlike
+// the mirror modes).  Lanes 0..NCOMP-1 of a group end up with the totals of components 0..NCOMP-1 and each updates its
+// own entry of x (the stream stores the destination row in lanes 0..3 of a group).
 template <int NCOMP, int LW>
-__device__ __forceinline__ void packed_slab(double v, int mk, double (&acc)[NCOMP], double *xs) {
+__device__ __forceinline__ void packed_slab(double v, int mk, double (&acc)[NCOMP], double *xs, int lane) {
+  const bool last = (mk & 0x8000) != 0;  // last slab of the step (wave-uniform)
+  const int dst = (mk >> 16) & 0xffff, l = lane % LW;
+  constexpr bool MERGED = NCOMP > 1 && NCOMP <= 4 && LW >= 8;
+  // the entry of x this lane will update is read FIRST: its LDS latency overlaps the gather + FMA + reduction chain
+  double old = 0.0;
+  int widx = 0;
+  const bool writer = last && dst && (MERGED ? l < NCOMP : l == 0);
+  if (MERGED) {
+    widx = (dst - 1) * NCOMP + l;
+    if (writer) old = xs[widx];
+  }
   const double *xj = xs + (mk & 0x7fff) * NCOMP;
 #pragma unroll
   for (int c = 0; c < NCOMP; ++c) acc[c] += v * xj[c];
-  if (mk & 0x8000) {  // last slab of the step (wave-uniform): reduce and update the rows of this step
+  if (last) {
+    if constexpr (MERGED) {
+      double r[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int c = 0; c < NCOMP; ++c) acc[c] = lane_group_sum<LW>(acc[c]);
-    const int dst = (mk >> 16) & 0xffff;
-    if (dst) {
-      double *xi = xs + (dst - 1) * NCOMP;
+      for (int c = 0; c < NCOMP; ++c) {
+        double t = acc[c];
+        t += dpp_f64<0xB1>(t);  // quad_perm [1,0,3,2]
+        t += dpp_f64<0x4E>(t);  // quad_perm [2,3,0,1]
+        r[c] = t;
+      }
+      const int q = lane & 3;
+      double w = q == 0 ? r[0] : (q == 1 ? r[1] : (q == 2 ? r[2] : r[3]));
+      w += dpp_f64<0x124>(w);                // row_ror:4  (lane i += lane i+4 of the 16-lane row)
+      if (LW >= 16) w += dpp_f64<0x128>(w);  // row_ror:8
+      if (LW >= 32) w += __shfl_xor(w, 16, 64);
+      if (LW >= 64) w += __shfl_xor(w, 32, 64);
+      if (writer) xs[widx] = old - w;
+    } else {
 #pragma unroll
-      for (int c = 0; c < NCOMP; ++c) xi[c] -= acc[c];
+      for (int c = 0; c < NCOMP; ++c) acc[c] = lane_group_sum<LW>(acc[c]);
+      if (writer) {
+        double *xi = xs + (dst - 1) * NCOMP;
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c) xi[c] -= acc[c];
+      }
     }
 #pragma unroll
     for (int c = 0; c < NCOMP; ++c) acc[c] = 0.0;
@@ -585,7 +618,7 @@ __device__ __forceinline__ void packed_sweep(int sa, int sb, const int32_t *__re
   }
 #define NSX_USE(V, M, S0)                                       \
   _Pragma("unroll") for (int k = 0; k < PF; ++k)                \
-    if ((S0) + k < sb) packed_slab<NCOMP, LW>(V[k], M[k], acc, xs);
+    if ((S0) + k < sb) packed_slab<NCOMP, LW>(V[k], M[k], acc, xs, lane);
   NSX_LOAD(va, ma, sa)
   for (int s0 = sa; s0 < sb; s0 += 2 * PF) {
     NSX_LOAD(vb, mb, s0 + PF)
@@ -601,10 +634,12 @@ template <int NCOMP, int LW, int PF>
 __global__ __launch_bounds__(64) void k_ilu_solve_packed(const int32_t *__restrict__ bptr, const int32_t *__restrict__ slab_ptr,
                                                          const int32_t *__restrict__ meta, const double *__restrict__ val,
                                                          const double *__restrict__ dinv, const double *__restrict__ b,
-                                                         double *__restrict__ x) {
+                                                         double *__restrict__ x, int prio_slabs) {
   extern __shared__ double xs[];
   const int blk = blockIdx.x, lane = threadIdx.x;
   const int r0 = bptr[blk], nloc = bptr[blk + 1] - r0;
+  // the kernel ends with its deepest block: waves of deep blocks get issue priority over the shallow ones sharing their SIMD
+  if (__builtin_amdgcn_readfirstlane(slab_ptr[2 * blk + 2] - slab_ptr[2 * blk]) > prio_slabs) __builtin_amdgcn_s_setprio(3);
   for (int t = lane; t < nloc * NCOMP; t += 64) xs[t] = b[(size_t)r0 * NCOMP + t];
   const int s0 = slab_ptr[2 * blk], s1 = slab_ptr[2 * blk + 1], s2 = slab_ptr[2 * blk + 2];
   packed_sweep<NCOMP, LW, PF>(s0, s1, meta, val, xs, lane);  // y = L^{-1} b
@@ -623,7 +658,7 @@ static void launch_packed(nsx_handle *h, const IluSchedule &s, const double *b, 
   static const int pf = getenv("NSX_PF") ? atoi(getenv("NSX_PF")) : 8;
 #define NSX_GO(PF_)                                                                                                              \
   hipLaunchKernelGGL((k_ilu_solve_packed<NCOMP, LW, PF_>), dim3(s.n_blocks), dim3(64), shm, h->stream, s.block_ptr.p, s.pk_slab_ptr.p, \
-                     s.pk_meta.p, s.pk_val.p, s.pk_dinv.p, b, x)
+                     s.pk_meta.p, s.pk_val.p, s.pk_dinv.p, b, x, s.prio_slabs)
   if (pf == 4) NSX_GO(4); else if (pf == 16) NSX_GO(16); else NSX_GO(8);
 #undef NSX_GO
 }
