@@ -67,6 +67,15 @@ int nsxh_mesh_partition(nsxh_mesh *, int n_parts, int n_sub);
 /* distribute_dofs + DoFRenumbering::component_wise(block {0,..,0,1}) (reference :62-69), numbered
  * subdomain by subdomain exactly as an MPI run with one rank per subdomain would be. */
 nsxh_dofs *nsxh_distribute_dofs(const nsxh_mesh *);
+/* Same, with a choice of the node order INSIDE each subdomain (deal.II leaves it to the cell traversal, the reference
+ * applies no renumbering of its own):
+ *   NSXH_ORDER_FIRST_TOUCH  cell by cell, vertices then lines (what nsxh_distribute_dofs does);
+ *   NSXH_ORDER_COLOUR       velocity nodes sorted by a greedy colouring of the subdomain's P2 graph: the per-rank ILU(0)
+ *                           gets a dependency graph as shallow as the number of colours.
+ * Ownership, rank ranges and the pressure numbering are the same for both. */
+enum { NSXH_ORDER_FIRST_TOUCH = 0, NSXH_ORDER_COLOUR = 1 };
+nsxh_dofs *nsxh_distribute_dofs_ordered(const nsxh_mesh *, int ordering);
+int nsxh_n_colours(const nsxh_dofs *);       /* colours used by NSXH_ORDER_COLOUR, 0 otherwise */
 void nsxh_dofs_free(nsxh_dofs *);
 
 int nsxh_dofs_per_cell(const nsxh_dofs *);   /* 15 (2D) / 34 (3D) */

@@ -102,12 +102,13 @@ struct IluSchedule {
   DevBuf<int32_t> blk_lvl_off;           // [n_blocks+1] offsets into fwd_lvl_ptr (levels per block), same for bwd
   DevBuf<int32_t> blk_lvl_off_b;
   int max_levels = 0;
-  // packed wave-per-block solve stream: slabs of 64 slots {value, meta}; meta = col | last_of_step<<15 | (dst_row+1)<<16
+  // packed solve stream (one wave per group of blocks): slabs of 64 slots {value, meta}; meta = col | last_of_step<<15 | (dst_row+1)<<16
   int lanes_per_row = 8;
   int64_t n_slabs = 0;
-  int prio_slabs = 1 << 30;      // blocks with more slabs than this run at raised wave priority
+  int blocks_per_wave = 1, n_waves = 0, max_wave_rows = 0;
   bool packed_ok = false;
-  DevBuf<int32_t> pk_slab_ptr;  // [2*n_blocks+1]: forward slabs, then backward slabs, per block
+  DevBuf<int32_t> pk_wave_blk;  // [n_waves*blocks_per_wave] blocks served by each wave (-1 = none)
+  DevBuf<int32_t> pk_slab_ptr;  // [2*n_waves+1]: forward slabs, then backward slabs, per wave
   DevBuf<int32_t> pk_meta;      // [n_slabs*64]
   DevBuf<int32_t> pk_slot_of;   // [nnz]: slot of every in-block off-diagonal CSR entry, -1 otherwise
   DevBuf<double> pk_val;        // [n_slabs*64] factor values in stream order (padding slots stay 0)
@@ -238,7 +239,7 @@ struct LaunchScope {
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // ---- kernels / steps implemented across the .hip files
-void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> &block_ptr, IluSchedule &s, int lanes_per_row);
+void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> &block_ptr, IluSchedule &s, int lanes_per_row, int blocks_per_wave);
 void build_schur_graph(nsx_handle *h);
 
 // assembly (nsx_assemble.hip)

@@ -65,7 +65,7 @@ static void build_gather(nsx_handle *h, const Csr &g, int n_cells, int per_r, co
   gm.src.upload(src, h->stream);
 }
 
-void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> &bptr, IluSchedule &s, int lanes_per_row) {
+void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> &bptr, IluSchedule &s, int lanes_per_row, int blocks_per_wave) {
   const int nb = (int)bptr.size() - 1;
   s.n_blocks = nb;
   s.block_ptr_h = bptr;
@@ -125,40 +125,95 @@ void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> 
   s.blk_lvl_off.upload(off_f, h->stream);
   s.blk_lvl_off_b.upload(off_b, h->stream);
 
-  // ---- packed stream for the wave-per-block solve (nsx_sparse.hip: k_ilu_solve_packed)
-  // A step = up to G = 64/LW independent rows of one level, LW lanes per row; it occupies K slabs of 64 slots,
-  // slot (k, lane) = entry lane%LW + k*LW of row lane/LW.  Rows without in-block entries need no work.
-  const int LW = lanes_per_row, G = 64 / LW;
+  // ---- packed stream of the solve kernel (nsx_sparse.hip: k_ilu_solve_packed)
+  // One wave serves BPW blocks (deep blocks are spread over different waves, shallow ones fill them up).  Per sweep
+  // direction the rows of those blocks that have in-block entries are list-scheduled: a step = up to G = 64/LW rows
+  // whose dependencies were finished in earlier steps, longest remaining dependency chain first, LW lanes per row.
+  // A step occupies K slabs of 64 slots, slot (k, lane) = entry lane%LW + k*LW of row-group lane/LW.  Columns and
+  // destinations are row indices into the wave's LDS copy of x (its blocks back to back).
+  const int LW = lanes_per_row, G = 64 / LW, BPW = std::max(1, blocks_per_wave);
   s.lanes_per_row = LW;
-  s.packed_ok = s.max_rows <= 32767;
-  if (!s.packed_ok) return;
-  std::vector<int32_t> slab_ptr(2 * (size_t)nb + 1, 0), meta, slot_of(g.nnz(), -1);
-  auto pack_dir = [&](int b, bool fwd) {
-    const int r0 = bptr[b], r1 = bptr[b + 1];
-    const auto &ptr = fwd ? f_ptr : b_ptr;
-    const auto &rows = fwd ? f_rows : b_rows;
-    const auto &off = fwd ? off_f : off_b;
-    for (int lv = off[b]; lv < off[b + 1]; ++lv) {
-      std::vector<int32_t> work;  // rows of this level that have in-block entries
-      for (int k = ptr[lv]; k < ptr[lv + 1]; ++k) {
-        const int i = rows[k];
-        bool any = false;
-        for (int q = g.rowptr[i]; q < g.rowptr[i + 1] && !any; ++q) {
-          const int j = g.colind[q];
-          any = fwd ? (j >= r0 && j < i) : (j > i && j < r1);
-        }
-        if (any) work.push_back(i);
+  s.blocks_per_wave = BPW;
+  const int nw = (nb + BPW - 1) / BPW;
+  s.n_waves = nw;
+  std::vector<int32_t> wave_blk((size_t)nw * BPW, -1);
+  {
+    std::vector<int32_t> order(nb), depth(nb);
+    for (int b = 0; b < nb; ++b) depth[b] = (off_f[b + 1] - off_f[b]) + (off_b[b + 1] - off_b[b]);
+    for (int b = 0; b < nb; ++b) order[b] = b;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return depth[x] > depth[y]; });
+    for (int p = 0; p < BPW; ++p)
+      for (int w = 0; w < nw; ++w) {
+        const int64_t idx = (int64_t)p * nw + ((p & 1) ? nw - 1 - w : w);
+        if (idx < nb) wave_blk[(size_t)w * BPW + p] = order[idx];
       }
-      for (size_t w0 = 0; w0 < work.size(); w0 += G) {
-        const int ng = (int)std::min<size_t>(G, work.size() - w0);
+  }
+  s.max_wave_rows = 0;
+  std::vector<int32_t> slab_ptr(2 * (size_t)nw + 1, 0), meta, slot_of(g.nnz(), -1);
+  std::vector<int32_t> xoff(g.n_rows, 0);  // LDS row index of every row (within its wave)
+  std::vector<int32_t> height(g.n_rows), indeg(g.n_rows), pend(g.n_rows);
+  int64_t n_steps = 0, max_steps = 0;
+  for (int w = 0; w < nw; ++w) {
+    int wr = 0;
+    for (int p = 0; p < BPW; ++p) {
+      const int b = wave_blk[(size_t)w * BPW + p];
+      if (b < 0) continue;
+      for (int i = bptr[b]; i < bptr[b + 1]; ++i) xoff[i] = wr++;
+    }
+    s.max_wave_rows = std::max(s.max_wave_rows, wr);
+    int64_t wave_steps = 0;
+    for (int dir = 0; dir < 2; ++dir) {
+      const bool fwd = dir == 0;
+      auto in_part = [&](int i, int j, int r0, int r1) { return fwd ? (j >= r0 && j < i) : (j > i && j < r1); };
+      // remaining chain length of every row (dependents first) and the number of unfinished dependencies
+      std::vector<std::pair<int32_t, int32_t>> ready;  // (height, row)
+      std::vector<int32_t> work;
+      for (int p = 0; p < BPW; ++p) {
+        const int b = wave_blk[(size_t)w * BPW + p];
+        if (b < 0) continue;
+        const int r0 = bptr[b], r1 = bptr[b + 1];
+        for (int i = r0; i < r1; ++i) height[i] = 0, indeg[i] = 0, pend[i] = 0;
+        for (int t = 0; t < r1 - r0; ++t) {
+          const int i = fwd ? r1 - 1 - t : r0 + t;  // dependents before their dependencies
+          for (int q = g.rowptr[i]; q < g.rowptr[i + 1]; ++q) {
+            const int j = g.colind[q];
+            if (!in_part(i, j, r0, r1)) continue;
+            height[j] = std::max(height[j], height[i] + 1);
+            indeg[i]++;
+          }
+        }
+        // rows without in-block entries are final from the start: they do not count as dependencies
+        for (int i = r0; i < r1; ++i) {
+          if (indeg[i] == 0) continue;
+          for (int q = g.rowptr[i]; q < g.rowptr[i + 1]; ++q) {
+            const int j = g.colind[q];
+            if (in_part(i, j, r0, r1) && indeg[j] > 0) pend[i]++;
+          }
+          work.push_back(i);
+        }
+      }
+      for (int i : work)
+        if (pend[i] == 0) ready.push_back({height[i], i});
+      size_t done = 0;
+      std::vector<int32_t> step_rows;
+      while (done < work.size()) {
+        if (ready.empty()) NSX_THROW(NSX_ERR_ARG, "internal: ILU schedule has a dependency cycle");
+        // pick the G rows with the longest remaining chains (ties: lowest row index, deterministic)
+        const size_t take = std::min<size_t>(G, ready.size());
+        std::partial_sort(ready.begin(), ready.begin() + take, ready.end(), [](const std::pair<int32_t, int32_t> &x, const std::pair<int32_t, int32_t> &y) {
+          return x.first != y.first ? x.first > y.first : x.second < y.second;
+        });
+        step_rows.clear();
+        for (size_t k = 0; k < take; ++k) step_rows.push_back(ready[k].second);
+        ready.erase(ready.begin(), ready.begin() + take);
+        const int ng = (int)step_rows.size();
         std::vector<std::vector<int32_t>> ent(ng);
         int K = 1;
         for (int gi = 0; gi < ng; ++gi) {
-          const int i = work[w0 + gi];
-          for (int q = g.rowptr[i]; q < g.rowptr[i + 1]; ++q) {
-            const int j = g.colind[q];
-            if (fwd ? (j >= r0 && j < i) : (j > i && j < r1)) ent[gi].push_back(q);
-          }
+          const int i = step_rows[gi];
+          const int b = (int)(std::upper_bound(bptr.begin(), bptr.end(), i) - bptr.begin()) - 1;
+          for (int q = g.rowptr[i]; q < g.rowptr[i + 1]; ++q)
+            if (in_part(i, g.colind[q], bptr[b], bptr[b + 1])) ent[gi].push_back(q);
           K = std::max(K, ((int)ent[gi].size() + LW - 1) / LW);
         }
         for (int k = 0; k < K; ++k) {
@@ -171,44 +226,46 @@ void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> 
               const size_t e = (size_t)l + (size_t)k * LW;
               if (e < ent[gi].size()) {
                 const int q = ent[gi][e];
-                m |= (g.colind[q] - r0);
+                m |= xoff[g.colind[q]];
                 slot_of[q] = (int32_t)(base + lane);
               }
-              if (k == K - 1 && l < 4) m |= (work[w0 + gi] - r0 + 1) << 16;  // lanes 0..3 of the group: one per component
+              if (k == K - 1 && l < 4) m |= (xoff[step_rows[gi]] + 1) << 16;  // lanes 0..3 of the group: one per component
             }
             meta[base + lane] = m;
           }
         }
+        ++wave_steps;
+        done += ng;
+        // release the dependents of the rows just scheduled (available from the next step on)
+        for (int gi = 0; gi < ng; ++gi) {
+          const int j = step_rows[gi];
+          const int b = (int)(std::upper_bound(bptr.begin(), bptr.end(), j) - bptr.begin()) - 1;
+          const int r0 = bptr[b], r1 = bptr[b + 1];
+          // the graph is structurally symmetric (FE pattern, B B^T): dependents of j = the other triangle of row j
+          for (int q = g.rowptr[j]; q < g.rowptr[j + 1]; ++q) {
+            const int i = g.colind[q];
+            if (!(fwd ? (i > j && i < r1) : (i < j && i >= r0))) continue;
+            if (indeg[i] == 0) continue;
+            if (--pend[i] == 0) ready.push_back({height[i], i});
+          }
+        }
       }
+      slab_ptr[2 * (size_t)w + 1 + dir] = (int32_t)(meta.size() / 64);
     }
-  };
-  for (int b = 0; b < nb; ++b) {
-    pack_dir(b, true);
-    slab_ptr[2 * (size_t)b + 1] = (int32_t)(meta.size() / 64);
-    pack_dir(b, false);
-    slab_ptr[2 * (size_t)b + 2] = (int32_t)(meta.size() / 64);
+    n_steps += wave_steps;
+    max_steps = std::max(max_steps, wave_steps);
   }
   s.n_slabs = (int64_t)meta.size() / 64;
-  {
-    int64_t mx = 0;
-    for (int b = 0; b < nb; ++b) mx = std::max<int64_t>(mx, slab_ptr[2 * b + 2] - slab_ptr[2 * b]);
-    const double frac = getenv("NSX_PRIO_FRAC") ? atof(getenv("NSX_PRIO_FRAC")) : 0.5;
-    s.prio_slabs = (int)(frac * (double)mx);
-  }
+  s.packed_ok = s.max_wave_rows <= 32766;
   if (getenv("NSX_DEBUG")) {
-    int64_t max_slabs = 0, steps = 0, max_steps = 0, used = 0;
-    for (int b = 0; b < nb; ++b) {
-      max_slabs = std::max<int64_t>(max_slabs, slab_ptr[2 * b + 2] - slab_ptr[2 * b]);
-      int64_t st = 0;
-      for (int64_t sl = slab_ptr[2 * b]; sl < slab_ptr[2 * b + 2]; ++sl) st += (meta[sl * 64] & 0x8000) ? 1 : 0;
-      steps += st;
-      max_steps = std::max(max_steps, st);
-    }
+    int64_t max_slabs = 0, used = 0;
+    for (int w = 0; w < nw; ++w) max_slabs = std::max<int64_t>(max_slabs, slab_ptr[2 * w + 2] - slab_ptr[2 * w]);
     for (int32_t v : slot_of) used += v >= 0;
-    fprintf(stderr, "[nsx] ilu schedule: rows %d blocks %d max_rows %d levels(max) %d LW %d slabs %lld (max/block %lld) steps %lld (max/block %lld) fill %.2f\n",
-            g.n_rows, nb, s.max_rows, s.max_levels, LW, (long long)s.n_slabs, (long long)max_slabs, (long long)steps, (long long)max_steps,
-            (double)used / (double)(s.n_slabs * 64));
+    fprintf(stderr, "[nsx] ilu schedule: rows %d blocks %d max_rows %d levels(max) %d LW %d BPW %d waves %d slabs %lld (max/wave %lld) steps %lld (max/wave %lld) fill %.2f\n",
+            g.n_rows, nb, s.max_rows, s.max_levels, LW, BPW, nw, (long long)s.n_slabs, (long long)max_slabs, (long long)n_steps, (long long)max_steps,
+            (double)used / (double)std::max<int64_t>(1, s.n_slabs * 64));
   }
+  s.pk_wave_blk.upload(wave_blk, h->stream);
   s.pk_slab_ptr.upload(slab_ptr, h->stream);
   s.pk_meta.upload(meta, h->stream);
   s.pk_slot_of.upload(slot_of, h->stream);
@@ -292,9 +349,10 @@ static void default_ranks(nsx_handle *h) {
 static void refresh_rank_products(nsx_handle *h) {
   h->rank_u.upload(h->rank_u_h, h->stream);
   h->dbar.alloc(h->rank_u_h.size() - 1);
-  const int lwF = getenv("NSX_LW_F") ? atoi(getenv("NSX_LW_F")) : 16, lwS = getenv("NSX_LW_S") ? atoi(getenv("NSX_LW_S")) : 32;
-  setup_ilu_schedule(h, h->gA.host, h->rank_u_h, h->schedF, lwF);
-  setup_ilu_schedule(h, h->gS.host, h->sblk_h.empty() ? h->rank_p_h : h->sblk_h, h->schedS, lwS);
+  const int lwF = getenv("NSX_LW_F") ? atoi(getenv("NSX_LW_F")) : 8, lwS = getenv("NSX_LW_S") ? atoi(getenv("NSX_LW_S")) : 32;
+  const int bpwF = getenv("NSX_BPW_F") ? atoi(getenv("NSX_BPW_F")) : 1, bpwS = getenv("NSX_BPW_S") ? atoi(getenv("NSX_BPW_S")) : 1;
+  setup_ilu_schedule(h, h->gA.host, h->rank_u_h, h->schedF, lwF, bpwF);
+  setup_ilu_schedule(h, h->gS.host, h->sblk_h.empty() ? h->rank_p_h : h->sblk_h, h->schedS, lwS, bpwS);
   h->prec_ready = false;
 }
 

@@ -543,13 +543,13 @@ __global__ __launch_bounds__(256) void k_ilu_solve(const int32_t *__restrict__ b
 }
 
 // ---- packed wave-per-block solve -------------------------------------------------------------------------------
-// One WAVE per rank block, the block's part of x in LDS, no workgroup barriers.  The factor is read as a linear
+// One WAVE per group of rank blocks (nsx_setup.hip), their part of x in LDS, no workgroup barriers.  The factor is read as a linear
 // stream of 64-slot slabs {value, meta} laid out at setup in exactly the order the wave consumes it (nsx_setup.hip),
 // so the only dependent chain per step is LDS gather -> FMA -> LW-lane DPP reduction -> LDS update; the global loads
 // are address-independent of x and are prefetched PF slabs ahead in registers.
 // Step end: sum the NCOMP partial sums over the LW lanes of each row group and update x.  After the two quad stages the
 // four lanes of a quad hold identical sums, so lane q of every quad keeps component q and the remaining stages run on
-// ONE register instead of NCOMP; they use row rotations by 4 and 8 (which preserve the position inside a quad, unlike
+// ONE register instead of NCOMP; they use row rotations by multiples of 4 (which preserve the position inside a quad, unlike
 // the mirror modes).  Lanes 0..NCOMP-1 of a group end up with the totals of components 0..NCOMP-1 and each updates its
 // own entry of x (the stream stores the destination row in lanes 0..3 of a group).
 template <int NCOMP, int LW>
@@ -580,8 +580,10 @@ __device__ __forceinline__ void packed_slab(double v, int mk, double (&acc)[NCOM
       }
       const int q = lane & 3;
       double w = q == 0 ? r[0] : (q == 1 ? r[1] : (q == 2 ? r[2] : r[3]));
-      w += dpp_f64<0x124>(w);                // row_ror:4  (lane i += lane i+4 of the 16-lane row)
-      if (LW >= 16) w += dpp_f64<0x128>(w);  // row_ror:8
+      // row_ror:n hands lane i the value of lane (i - n) mod 16 of its 16-lane row
+      if (LW == 8) w += dpp_f64<0x12C>(w);   // row_ror:12: lane i += lane i+4 (the second quad of the 8-lane group)
+      if (LW >= 16) w += dpp_f64<0x124>(w);  // row_ror:4 then row_ror:8: every lane ends with the sum of its residue class mod 4
+      if (LW >= 16) w += dpp_f64<0x128>(w);
       if (LW >= 32) w += __shfl_xor(w, 16, 64);
       if (LW >= 64) w += __shfl_xor(w, 32, 64);
       if (writer) xs[widx] = old - w;
@@ -631,34 +633,49 @@ __device__ __forceinline__ void packed_sweep(int sa, int sb, const int32_t *__re
 }
 
 template <int NCOMP, int LW, int PF>
-__global__ __launch_bounds__(64) void k_ilu_solve_packed(const int32_t *__restrict__ bptr, const int32_t *__restrict__ slab_ptr,
-                                                         const int32_t *__restrict__ meta, const double *__restrict__ val,
-                                                         const double *__restrict__ dinv, const double *__restrict__ b,
-                                                         double *__restrict__ x, int prio_slabs) {
+__global__ __launch_bounds__(64) void k_ilu_solve_packed(int bpw, const int32_t *__restrict__ wave_blk, const int32_t *__restrict__ bptr,
+                                                         const int32_t *__restrict__ slab_ptr, const int32_t *__restrict__ meta,
+                                                         const double *__restrict__ val, const double *__restrict__ dinv,
+                                                         const double *__restrict__ b, double *__restrict__ x) {
   extern __shared__ double xs[];
-  const int blk = blockIdx.x, lane = threadIdx.x;
-  const int r0 = bptr[blk], nloc = bptr[blk + 1] - r0;
-  // the kernel ends with its deepest block: waves of deep blocks get issue priority over the shallow ones sharing their SIMD
-  if (__builtin_amdgcn_readfirstlane(slab_ptr[2 * blk + 2] - slab_ptr[2 * blk]) > prio_slabs) __builtin_amdgcn_s_setprio(3);
-  for (int t = lane; t < nloc * NCOMP; t += 64) xs[t] = b[(size_t)r0 * NCOMP + t];
-  const int s0 = slab_ptr[2 * blk], s1 = slab_ptr[2 * blk + 1], s2 = slab_ptr[2 * blk + 2];
+  const int w = blockIdx.x, lane = threadIdx.x;
+  const int s0 = slab_ptr[2 * w], s1 = slab_ptr[2 * w + 1], s2 = slab_ptr[2 * w + 2];
+  for (int p = 0, xo = 0; p < bpw; ++p) {
+    const int blk = wave_blk[w * bpw + p];
+    if (blk < 0) continue;
+    const int r0 = bptr[blk], nloc = bptr[blk + 1] - r0;
+    for (int t = lane; t < nloc * NCOMP; t += 64) xs[xo * NCOMP + t] = b[(size_t)r0 * NCOMP + t];
+    xo += nloc;
+  }
   packed_sweep<NCOMP, LW, PF>(s0, s1, meta, val, xs, lane);  // y = L^{-1} b
-  for (int t = lane; t < nloc; t += 64) {                   // y *= D^{-1}
-    const double d = dinv[r0 + t];
+  for (int p = 0, xo = 0; p < bpw; ++p) {                    // y *= D^{-1}
+    const int blk = wave_blk[w * bpw + p];
+    if (blk < 0) continue;
+    const int r0 = bptr[blk], nloc = bptr[blk + 1] - r0;
+    for (int t = lane; t < nloc; t += 64) {
+      const double d = dinv[r0 + t];
 #pragma unroll
-    for (int c = 0; c < NCOMP; ++c) xs[t * NCOMP + c] *= d;
+      for (int c = 0; c < NCOMP; ++c) xs[(xo + t) * NCOMP + c] *= d;
+    }
+    xo += nloc;
   }
   packed_sweep<NCOMP, LW, PF>(s1, s2, meta, val, xs, lane);  // x = U^{-1} y
-  for (int t = lane; t < nloc * NCOMP; t += 64) x[(size_t)r0 * NCOMP + t] = xs[t];
+  for (int p = 0, xo = 0; p < bpw; ++p) {
+    const int blk = wave_blk[w * bpw + p];
+    if (blk < 0) continue;
+    const int r0 = bptr[blk], nloc = bptr[blk + 1] - r0;
+    for (int t = lane; t < nloc * NCOMP; t += 64) x[(size_t)r0 * NCOMP + t] = xs[xo * NCOMP + t];
+    xo += nloc;
+  }
 }
 
 template <int NCOMP, int LW>
 static void launch_packed(nsx_handle *h, const IluSchedule &s, const double *b, double *x) {
-  const size_t shm = (size_t)s.max_rows * NCOMP * sizeof(double);
+  const size_t shm = (size_t)s.max_wave_rows * NCOMP * sizeof(double);
   static const int pf = getenv("NSX_PF") ? atoi(getenv("NSX_PF")) : 8;
-#define NSX_GO(PF_)                                                                                                              \
-  hipLaunchKernelGGL((k_ilu_solve_packed<NCOMP, LW, PF_>), dim3(s.n_blocks), dim3(64), shm, h->stream, s.block_ptr.p, s.pk_slab_ptr.p, \
-                     s.pk_meta.p, s.pk_val.p, s.pk_dinv.p, b, x, s.prio_slabs)
+#define NSX_GO(PF_)                                                                                                               \
+  hipLaunchKernelGGL((k_ilu_solve_packed<NCOMP, LW, PF_>), dim3(s.n_waves), dim3(64), shm, h->stream, s.blocks_per_wave, s.pk_wave_blk.p, \
+                     s.block_ptr.p, s.pk_slab_ptr.p, s.pk_meta.p, s.pk_val.p, s.pk_dinv.p, b, x)
   if (pf == 4) NSX_GO(4); else if (pf == 16) NSX_GO(16); else NSX_GO(8);
 #undef NSX_GO
 }
@@ -678,10 +695,10 @@ static void launch_ilu_solve(nsx_handle *h, const DevCsr &g, const IluSchedule &
 
 void ilu_solve(nsx_handle *h, const DevCsr &g, const IluSchedule &s, const double *lu, const double *b, double *x, int ncomp,
                const char *name) {
-  const bool packed = s.packed_ok && (size_t)s.max_rows * ncomp * sizeof(double) <= 64 * 1024;
+  const bool packed = s.packed_ok && (size_t)s.max_wave_rows * ncomp * sizeof(double) <= 64 * 1024;
   // algorithmic bytes: the CSR factor once (12 B/entry) + rhs/solution vectors; the packed stream moves 768 B per slab
   LaunchScope ls(h, name, 12.0 * g.nnz() + (double)g.n_rows() * (4 + 16.0 * ncomp));
-  if (packed && (size_t)s.max_rows * ncomp * sizeof(double) <= 64 * 1024) {
+  if (packed) {
     const int lw = s.lanes_per_row;
 #define NSX_PK(NC)                                              \
     if (lw == 8) return launch_packed<NC, 8>(h, s, b, x);       \

@@ -37,6 +37,8 @@ def _lib():
         "nsxh_mesh_subdomain": (_i32p, [vp]),
         "nsxh_mesh_partition": (C.c_int, [vp, C.c_int, C.c_int]),
         "nsxh_distribute_dofs": (vp, [vp]),
+        "nsxh_distribute_dofs_ordered": (vp, [vp, C.c_int]),
+        "nsxh_n_colours": (C.c_int, [vp]),
         "nsxh_dofs_free": (None, [vp]),
         "nsxh_dofs_per_cell": (C.c_int, [vp]),
         "nsxh_n_nodes_p2": (C.c_int, [vp]),
@@ -149,10 +151,16 @@ class Mesh:
 class DoFs:
     """Taylor-Hood P2/P1 DoF tables (FESystem local order; velocity block then pressure block)."""
 
-    def __init__(self, mesh):
+    ORDERINGS = {"first_touch": 0, "colour": 1}
+
+    def __init__(self, mesh, ordering="first_touch"):
         L = _lib()
         self._lib, self.mesh = L, mesh
-        self._h = h = L.nsxh_distribute_dofs(mesh._h)
+        self.ordering = ordering
+        self._h = h = L.nsxh_distribute_dofs_ordered(mesh._h, self.ORDERINGS[ordering])
+        if not h:
+            raise ValueError("nsxh_distribute_dofs_ordered failed")
+        self.n_colours = L.nsxh_n_colours(h)
         self.dim = mesh.dim
         nc = mesh.cells.shape[0]
         self.n_cells = nc

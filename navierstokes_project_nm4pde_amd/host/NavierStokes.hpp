@@ -94,7 +94,7 @@ public:
     out() << "  DoFs per cell              = " << (dim == 3 ? 34 : 15) << std::endl;
     out() << "  Quadrature points per cell = " << nsxh_tables_n_q(t) << std::endl;
     out() << "Initializing the DoF handler" << std::endl;
-    dofs = nsxh_distribute_dofs(mesh);
+    dofs = nsxh_distribute_dofs_ordered(mesh, NSXH_ORDER_COLOUR);  // shallow per-rank ILU(0) dependency graphs
     n_u = nsxh_n_u(dofs);
     n_p = nsxh_n_p(dofs);
     out() << "  Number of DoFs: " << std::endl << "    velocity = " << n_u << std::endl << "    pressure = " << n_p << std::endl

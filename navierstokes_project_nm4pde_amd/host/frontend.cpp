@@ -611,7 +611,7 @@ extern "C" nsxh_mesh *nsxh_mesh_read_msh(const char *path) { return read_msh_imp
 
 // ---------------------------------------------------------------- DoF handler
 struct nsxh_dofs {
-  int dim = 0, n_cells = 0, dpc = 0, n2 = 0, n1 = 0, n_sub = 1;
+  int dim = 0, n_cells = 0, dpc = 0, n2 = 0, n1 = 0, n_sub = 1, n_colours = 0;
   const nsxh_mesh *mesh = nullptr;
   std::vector<int32_t> cell_dofs;
   std::vector<int32_t> cell_nodes2, cell_nodes1;  // scalar connectivity
@@ -624,9 +624,56 @@ struct nsxh_dofs {
   bool have_ref[4] = {false, false, false, false};
 };
 
+// NSXH_ORDER_COLOUR: renumber the P2 nodes inside every subdomain by greedy colour (nodes of one colour share no cell
+// inside the subdomain).  The ILU(0) dependency graph of a rank block is then only as deep as the number of colours
+// (13 on the 3D channel meshes against up to 93 levels with first-touch numbering), which is what bounds the
+// triangular solves on the GPU.  Ownership, the rank ranges and the pressure numbering are untouched.
+static void renumber_by_colour(nsxh_dofs *d, int np2) {
+  const int nc = d->n_cells, n2 = (int)d->node_owner.size();
+  std::vector<int32_t> nptr(n2 + 1, 0), ncell;
+  for (size_t k = 0; k < d->cell_nodes2.size(); ++k) nptr[d->cell_nodes2[k] + 1]++;
+  for (int i = 0; i < n2; ++i) nptr[i + 1] += nptr[i];
+  ncell.resize(nptr[n2]);
+  {
+    std::vector<int32_t> fill(nptr.begin(), nptr.end() - 1);
+    for (int c = 0; c < nc; ++c)
+      for (int a = 0; a < np2; ++a) ncell[fill[d->cell_nodes2[(size_t)c * np2 + a]]++] = c;
+  }
+  std::vector<int32_t> colour(n2, -1), perm(n2);
+  std::vector<uint8_t> used;
+  int max_col = 0;
+  for (int i = 0; i < n2; ++i) {
+    used.assign(max_col + 2, 0);
+    for (int k = nptr[i]; k < nptr[i + 1]; ++k)
+      for (int a = 0; a < np2; ++a) {
+        const int j = d->cell_nodes2[(size_t)ncell[k] * np2 + a];
+        if (j != i && d->node_owner[j] == d->node_owner[i] && colour[j] >= 0) used[colour[j]] = 1;
+      }
+    int c = 0;
+    while (used[c]) ++c;
+    colour[i] = c;
+    max_col = std::max(max_col, c + 1);
+  }
+  for (int s = 0; s < d->n_sub; ++s) {
+    const int r0 = d->owned_u_ptr[s], r1 = d->owned_u_ptr[s + 1];
+    std::vector<int32_t> idx(r1 - r0);
+    std::iota(idx.begin(), idx.end(), r0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) { return colour[a] < colour[b]; });
+    for (int k = 0; k < r1 - r0; ++k) perm[idx[k]] = r0 + k;
+  }
+  d->n_colours = max_col;
+  for (auto &v : d->vertex_node)
+    if (v >= 0) v = perm[v];
+  for (auto &kv : d->edge_node) kv.second = perm[kv.second];
+  for (auto &v : d->cell_nodes2) v = perm[v];
+}
+
 extern "C" {
 
-nsxh_dofs *nsxh_distribute_dofs(const nsxh_mesh *m) {
+nsxh_dofs *nsxh_distribute_dofs(const nsxh_mesh *m) { return nsxh_distribute_dofs_ordered(m, NSXH_ORDER_FIRST_TOUCH); }
+
+nsxh_dofs *nsxh_distribute_dofs_ordered(const nsxh_mesh *m, int ordering) {
+  if (!m || (ordering != NSXH_ORDER_FIRST_TOUCH && ordering != NSXH_ORDER_COLOUR)) return nullptr;
   auto *d = new nsxh_dofs;
   const int dim = m->dim, nv = dim + 1, nl = dim == 2 ? 3 : 6, nc = m->n_cells();
   d->dim = dim;
@@ -679,6 +726,7 @@ nsxh_dofs *nsxh_distribute_dofs(const nsxh_mesh *m) {
   }
   d->n2 = next2;
   d->n1 = next1;
+  if (ordering == NSXH_ORDER_COLOUR) renumber_by_colour(d, np2);
   const int32_t n_u = dim * next2;
   d->cell_dofs.resize((size_t)nc * d->dpc);
   d->cell_coords.resize((size_t)nc * nv * dim);
@@ -724,6 +772,7 @@ const int32_t *nsxh_pnode_owner(const nsxh_dofs *d) { return d->pnode_owner.data
 const int32_t *nsxh_owned_u_ptr(const nsxh_dofs *d) { return d->owned_u_ptr.data(); }
 const int32_t *nsxh_owned_p_ptr(const nsxh_dofs *d) { return d->owned_p_ptr.data(); }
 int nsxh_n_subdomains(const nsxh_dofs *d) { return d->n_sub; }
+int nsxh_n_colours(const nsxh_dofs *d) { return d->n_colours; }
 
 int nsxh_boundary_dofs(nsxh_dofs *d, int boundary_id, const int32_t **dofs) {
   auto it = d->bdofs.find(boundary_id);

@@ -26,7 +26,7 @@ def built():
 class Problem:
     """Mesh + DoFs + tables + parameters of one test configuration."""
 
-    def __init__(self, kind, dim, level=1, n_sub=1, nu=1e-3, deltat=None, **kw):
+    def __init__(self, kind, dim, level=1, n_sub=1, nu=1e-3, deltat=None, ordering="first_touch", **kw):
         from navierstokes_project_nm4pde_amd.frontend import DoFs, Mesh, Tables
         if kind == "cylinder":
             self.mesh = Mesh.cylinder(dim, level, **kw)
@@ -38,7 +38,7 @@ class Problem:
             raise ValueError(kind)
         if n_sub > 1:
             self.mesh.partition(1, n_sub)
-        self.dofs = DoFs(self.mesh)
+        self.dofs = DoFs(self.mesh, ordering)
         self.tables = Tables(dim)
         self.dim, self.nu, self.kind = dim, nu, kind
         self.deltat = deltat if deltat is not None else (2e-4 if dim == 3 else 1e-2)

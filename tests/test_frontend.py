@@ -90,6 +90,40 @@ def test_single_rank_numbering_is_first_touch():
 
 
 @pytest.mark.parametrize("dim", [2, 3])
+def test_colour_ordering_is_a_rank_local_renumbering(dim):
+    m = Mesh.cylinder(dim, 1).partition(1, 4)
+    d0, d1 = DoFs(m), DoFs(m, "colour")
+    assert d0.n_colours == 0 and d1.n_colours >= (6 if dim == 2 else 10)   # a cell's P2 nodes are mutually adjacent
+    nv, nl = dim + 1, 3 if dim == 2 else 6
+    cols = [(dim + 1) * v for v in range(nv)] + [nv * (dim + 1) + dim * l for l in range(nl)]
+    n0, n1 = d0.cell_dofs[:, cols] // dim, d1.cell_dofs[:, cols] // dim
+    # a permutation of the P2 nodes that keeps every node inside its owner's range; pressure untouched
+    perm = np.full(d0.n_nodes_p2, -1)
+    perm[n0.ravel()] = n1.ravel()
+    assert sorted(perm.tolist()) == list(range(d0.n_nodes_p2))
+    assert (d1.node_owner == d0.node_owner).all() and (d1.node_owner[perm] == d0.node_owner).all()
+    assert (d1.owned_u_ptr == d0.owned_u_ptr).all() and (d1.owned_p_ptr == d0.owned_p_ptr).all()
+    pc = [(dim + 1) * v + dim for v in range(nv)]
+    assert (d1.cell_dofs[:, pc] == d0.cell_dofs[:, pc]).all()
+    assert np.allclose(d1.support_points[d1.cell_dofs], d0.support_points[d0.cell_dofs])
+    # inside a rank the nodes come colour by colour: a run of consecutive nodes without mutual adjacency.  Hence the
+    # ILU(0) dependency depth of a rank block (longest chain i1 < i2 < ... of adjacent nodes) is at most n_colours.
+    import scipy.sparse as sp
+    rows = np.repeat(n1, n1.shape[1], axis=1).ravel()
+    colsn = np.tile(n1, (1, n1.shape[1])).ravel()
+    A = sp.csr_matrix((np.ones(len(rows)), (rows, colsn)), shape=(d1.n_nodes_p2,) * 2)
+    A.sum_duplicates()
+    depth = np.zeros(d1.n_nodes_p2, dtype=int)
+    for i in range(d1.n_nodes_p2):
+        nb = A.indices[A.indptr[i]:A.indptr[i + 1]]
+        nb = nb[(nb < i) & (d1.node_owner[nb] == d1.node_owner[i])]
+        depth[i] = depth[nb].max() + 1 if len(nb) else 0
+    assert depth.max() + 1 <= d1.n_colours
+    assert d1.boundary_dofs(3).size == d0.boundary_dofs(3).size
+    assert np.allclose(np.sort(d1.support_points[d1.boundary_dofs(3)], axis=0), np.sort(d0.support_points[d0.boundary_dofs(3)], axis=0))
+
+
+@pytest.mark.parametrize("dim", [2, 3])
 def test_reference_sparsity_matches_cell_couplings(dim):
     import scipy.sparse as sp
     m = Mesh.cylinder(dim, 1)

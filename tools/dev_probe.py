@@ -1,3 +1,4 @@
+import os
 """Development probe run on the GPU box: a failing scenario + first timings of the ~1M-DoF 3D cylinder."""
 import sys, time, json, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,7 +27,7 @@ if what == "cube":
 else:
     lvl, nsub, ssub = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
     m = Mesh.cylinder(3, lvl).partition(1, nsub)
-    d, tb = DoFs(m), Tables(3)
+    d, tb = DoFs(m, os.environ.get("NSX_PROBE_ORDER", "colour")), Tables(3)
     print("dofs", d.n_dofs, "cells", d.n_cells, flush=True)
     t0 = time.time(); dev = nsx.Nsx(d, tb, 1e-3, 2e-4); print("setup %.1fs" % (time.time() - t0), flush=True)
     if ssub > 0:
