@@ -197,6 +197,171 @@ void v_add_and_dot(nsx_handle *h, Span sp, double *d, double a, int aslot, const
   after_reduction(h, slot, nb);
 }
 
+// ---- modified Gram-Schmidt sweep in ONE persistent launch -----------------------------------------------------------
+// deal.II's SolverGMRES orthogonalises the new Krylov vector w with the chain  h(0) = w.v_0 ;
+// h(i+1) = w.add_and_dot(-h(i), v_i, v_{i+1}) ; |w|^2 = w.add_and_dot(-h(dim-1), v_{dim-1}, w): dim+1 dependent global
+// reductions.  As separate launches every link streams w (read + write) and two basis vectors, 32 B per entry; here the
+// grid is co-resident (cooperative launch), every thread keeps its entries of w and of the current v_i in registers for
+// the whole sweep, and a link costs ONE read of the next basis vector (8 B per entry, prefetched before the wait) plus a
+// grid-wide exchange of the partial sums.  The exchange uses no atomics on shared counters: workgroup b stores the bit
+// pattern of its partial sum in mailbox[step][b] (initially MGS_EMPTY), workgroup 0 waits for all of them, adds them in
+// a fixed order and stores the total in total[step], where every workgroup picks it up.  The arithmetic of each entry is
+// that of the chain (w += (-h) v_i), sums are fixed-order, so results do not depend on timing.
+// Every wait is bounded by a wall-clock timeout that raises *err, so the grid always drains.
+constexpr int MGS_E = 10;         // entries of w per thread
+constexpr int MGS_MAX_WG = 512;
+constexpr int MGS_STEPS = 32;     // >= max_n_tmp_vectors + 1
+constexpr unsigned long long MGS_EMPTY = ~0ull;
+constexpr size_t MGS_REGION = (size_t)MGS_STEPS * MGS_MAX_WG + MGS_STEPS;  // words per mailbox region (+ the totals)
+
+struct MgsArgs {
+  const double *v[MGS_STEPS];
+};
+
+__device__ __forceinline__ unsigned long long mgs_bits(double v) {
+  unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  return b == MGS_EMPTY ? 0x7ff8000000000000ull : b;  // a NaN with the sentinel's bit pattern becomes the canonical NaN
+}
+__device__ __forceinline__ unsigned long long mgs_wait(const unsigned long long *p, int *err) {
+  unsigned long long b = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (b != MGS_EMPTY) return b;
+  const unsigned long long t0 = wall_clock64();  // 100 MHz
+  while ((b = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == MGS_EMPTY) {
+    __builtin_amdgcn_s_sleep(1);
+    if (wall_clock64() - t0 > 200000000ull) {  // 2 s: something is badly wrong; give up instead of hanging the GPU
+      *err = 1;
+      return 0;
+    }
+  }
+  return b;
+}
+// sum over the 64 lanes of the wave in a fixed order, result wave-uniform: four DPP stages inside each row of 16 lanes,
+// then the four row sums are read out of lanes 0/16/32/48
+__device__ __forceinline__ double mgs_wave_sum(double v) {
+  v += dpp_f64<0xB1>(v);
+  v += dpp_f64<0x4E>(v);
+  v += dpp_f64<0x141>(v);
+  v += dpp_f64<0x140>(v);
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  double r[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) r[k] = __hiloint2double(__builtin_amdgcn_readlane(hi, 16 * k), __builtin_amdgcn_readlane(lo, 16 * k));
+  return (r[0] + r[1]) + (r[2] + r[3]);
+}
+// fixed-order sum over the 256 threads of the block, result in every thread
+__device__ __forceinline__ double mgs_block_sum(double v, double *sh) {
+  v = mgs_wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void k_mgs(int n, int split, int gap, double *__restrict__ w, MgsArgs V, int dim,
+                                             unsigned long long *box, unsigned long long *box_next, int reset_wg, int reset_steps,
+                                             double *__restrict__ scal_out, int *err) {
+  __shared__ double sh[2][4];  // two buffers: a wave may start the next sum while a slower one still reads this one
+  __shared__ unsigned long long bc;
+  const int nwg = gridDim.x, wg = blockIdx.x, T = nwg * 256, t = wg * 256 + threadIdx.x;
+  unsigned long long *total = box + (size_t)MGS_STEPS * MGS_MAX_WG, *total_next = box_next + (size_t)MGS_STEPS * MGS_MAX_WG;
+  // leave the other region empty for the next launch (stream order makes this visible to it): its last user filled
+  // reset_steps rows of reset_wg mailboxes, possibly more than this grid has workgroups
+  for (int q = t; q < reset_steps * reset_wg; q += T) box_next[(size_t)(q / reset_wg) * MGS_MAX_WG + q % reset_wg] = MGS_EMPTY;
+  if (wg == 0 && threadIdx.x < MGS_STEPS) total_next[threadIdx.x] = MGS_EMPTY;
+  double wv[MGS_E], vc[MGS_E], vn[MGS_E];
+  int idx[MGS_E];
+#pragma unroll
+  for (int k = 0; k < MGS_E; ++k) {
+    const int i0 = t + k * T;
+    idx[k] = i0 < n ? i0 + (i0 >= split ? gap : 0) : -1;
+    wv[k] = idx[k] >= 0 ? w[idx[k]] : 0.0;
+    vc[k] = idx[k] >= 0 ? V.v[0][idx[k]] : 0.0;
+    vn[k] = 0.0;
+  }
+  for (int s = 0; s <= dim; ++s) {
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < MGS_E; ++k) acc += wv[k] * (s < dim ? vc[k] : wv[k]);
+    if (s + 1 < dim) {  // the next basis vector is on its way while the sums are exchanged
+      const double *__restrict__ vp = V.v[s + 1];
+#pragma unroll
+      for (int k = 0; k < MGS_E; ++k) vn[k] = idx[k] >= 0 ? vp[idx[k]] : 0.0;
+    }
+    const double part = mgs_block_sum(acc, sh[0]);
+    unsigned long long *row = box + (size_t)s * MGS_MAX_WG;
+    if (threadIdx.x == 0) __hip_atomic_store(row + wg, mgs_bits(part), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // workgroup 0 collects the partial sums, adds them in a fixed order and publishes the total; the others wait for
+    // that one word (letting every workgroup read all mailboxes saves a trip through memory on paper but measured
+    // slower: 64 us against 57 us per sweep of 9 links at 1.04 M entries, the polling traffic gets in its own way)
+    if (wg == 0) {
+      double a = 0.0, b = 0.0;
+      if ((int)threadIdx.x < nwg) a = __longlong_as_double((long long)mgs_wait(row + threadIdx.x, err));
+      if ((int)threadIdx.x + 256 < nwg) b = __longlong_as_double((long long)mgs_wait(row + threadIdx.x + 256, err));
+      const double tot = mgs_block_sum(a + b, sh[1]);
+      if (threadIdx.x == 0) {
+        scal_out[s] = tot;
+        __hip_atomic_store(total + s, mgs_bits(tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (threadIdx.x == 0) bc = mgs_wait(total + s, err);
+    __syncthreads();
+    const double hs = __longlong_as_double((long long)bc);
+    if (s < dim) {
+      const double alpha = -1.0 * hs;
+#pragma unroll
+      for (int k = 0; k < MGS_E; ++k) {
+        wv[k] += alpha * vc[k];
+        vc[k] = vn[k];
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < MGS_E; ++k)
+    if (idx[k] >= 0) w[idx[k]] = wv[k];
+}
+
+static void mgs_setup(nsx_handle *h) {
+  if (h->mgs_box.p) return;
+  h->mgs_max_wg = 0;
+  if (getenv("NSX_MGS") && atoi(getenv("NSX_MGS")) == 0) return;
+  int coop = 0, cus = 0, per_cu = 0;
+  HIP_CHECK(hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, h->prm.device));
+  HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->prm.device));
+  if (!coop) return;
+  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mgs, 256, 0));
+  h->mgs_box.alloc(2 * MGS_REGION);
+  HIP_CHECK(hipMemsetAsync(h->mgs_box.p, 0xff, 2 * MGS_REGION * sizeof(unsigned long long), h->stream));
+  h->mgs_max_wg = std::min(MGS_MAX_WG, per_cu * cus);
+}
+
+void v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int slot0) {
+  const int n = sp.n;
+  if (!h->comm) mgs_setup(h);
+  const int nwg = std::max(1, std::min(h->mgs_max_wg, cdiv(n, 256 * 4)));
+  if (h->comm || h->mgs_max_wg == 0 || dim + 1 > MGS_STEPS || (int64_t)nwg * 256 * MGS_E < n) {
+    // one launch per link: the distributed solve needs an all-reduce after every dot product
+    v_dot(h, sp, w, vs[0], slot0);
+    for (int i = 1; i < dim; ++i) v_add_and_dot(h, sp, w, -1.0, slot0 + i - 1, vs[i - 1], vs[i], slot0 + i);
+    v_add_and_dot(h, sp, w, -1.0, slot0 + dim - 1, vs[dim - 1], w, slot0 + dim);
+    return;
+  }
+  LaunchScope ls(h, "mgs_sweep", 8.0 * n * (dim + 2));
+  MgsArgs V;
+  for (int i = 0; i < dim; ++i) V.v[i] = vs[i];
+  for (int i = dim; i < MGS_STEPS; ++i) V.v[i] = nullptr;
+  int n_ = n, split = sp.split, gap = sp.gap, dim_ = dim;
+  unsigned long long *box = h->mgs_box.p + (size_t)h->mgs_parity * MGS_REGION, *box_next = h->mgs_box.p + (size_t)(1 - h->mgs_parity) * MGS_REGION;
+  double *out = h->scal.p + slot0;
+  int *err = (int *)(h->pub_dev + N_SLOTS + 2);  // mapped host word, checked by read_scalars
+  int reset_wg = h->mgs_used_wg[1 - h->mgs_parity], reset_steps = h->mgs_used_steps[1 - h->mgs_parity];
+  void *args[] = {&n_, &split, &gap, &w, &V, &dim_, &box, &box_next, &reset_wg, &reset_steps, &out, &err};
+  HIP_CHECK(hipLaunchCooperativeKernel((const void *)k_mgs, dim3(nwg), dim3(256), args, 0, h->stream));
+  h->mgs_used_wg[h->mgs_parity] = nwg;
+  h->mgs_used_steps[h->mgs_parity] = dim + 1;
+  h->mgs_used_wg[1 - h->mgs_parity] = h->mgs_used_steps[1 - h->mgs_parity] = 0;
+  h->mgs_parity ^= 1;
+  for (int i = 0; i <= dim; ++i) h->slot_nb[slot0 + i] = 0;
+}
+
 // ---- element-wise
 __global__ __launch_bounds__(256) void k_axpby(int n, int split, int gap, double *__restrict__ d, SRef s, SRef a, const double *__restrict__ v,
                                                const double *__restrict__ scal, const double *__restrict__ partial, int mode) {
@@ -326,6 +491,7 @@ void read_scalars(nsx_handle *h, int slot0, int count, double *out) {
     }
   }
   for (int i = 0; i < count; ++i) out[i] = h->pub_host[slot0 + i];
+  if (*(volatile int *)(h->pub_host + N_SLOTS + 2)) NSX_THROW(NSX_ERR_HIP, "Gram-Schmidt sweep: a workgroup waited more than 2 s for a partial sum");
 }
 void write_scalar(nsx_handle *h, int slot, double v) {
   HIP_CHECK(hipStreamSynchronize(h->stream));

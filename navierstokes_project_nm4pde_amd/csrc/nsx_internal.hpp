@@ -201,6 +201,10 @@ struct nsx_handle {
   double *pub_host = nullptr, *pub_dev = nullptr;  // [N_SLOTS] values, then the flag word
   unsigned long long pub_seq = 0;
   nsx::DevBuf<unsigned int> pub_counter;
+  // persistent Gram-Schmidt kernel (nsx_blas.hip: k_mgs): two mailbox regions used alternately by successive launches
+  nsx::DevBuf<unsigned long long> mgs_box;
+  int mgs_used_wg[2] = {0, 0}, mgs_used_steps[2] = {0, 0};  // what the last launch on each region filled
+  int mgs_parity = 0, mgs_max_wg = 0;  // mgs_max_wg = 0: cooperative launch unavailable, the launch-per-step chain is used
   // ---- force evaluation (compute_forces): obstacle faces + face-quadrature tables
   int ff_n = 0, ff_nq = 0;
   nsx::DevBuf<int32_t> ff_cells, ff_lf;
@@ -268,6 +272,16 @@ struct Span {
 };
 inline Span blk_span(const nsx_handle *h) { return Span(h->n_u + h->n_p, h->n_u, h->g_u); }
 
+// DPP lane permutation of a double (two 32-bit moves, pure VALU); CTRL as in the ISA: 0xB1/0x4E quad_perm,
+// 0x141 row_half_mirror, 0x140 row_mirror, 0x120+n row_ror:n
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+
 // BLAS-1 (nsx_blas.hip): scalars live in h->scal[slot]
 void v_copy(nsx_handle *h, int n, double *d, const double *s);  // raw copy of n contiguous entries
 void v_zero(nsx_handle *h, int n, double *d);
@@ -280,6 +294,8 @@ void v_scale_vec(nsx_handle *h, int n, double *d, const double *f);
 void v_dot(nsx_handle *h, Span n, const double *a, const double *b, int slot);               // scal[slot] = a.b
 void v_add_and_dot(nsx_handle *h, Span n, double *d, double a, int aslot, const double *v, const double *w, int slot);
                                                                                             // d += a*scal[aslot]*v ; scal[slot] = d.w
+// modified Gram-Schmidt sweep of SolverGMRES (w against v_0..v_{dim-1}): scal[slot0+i] = h(i), scal[slot0+dim] = |w|^2 afterwards
+void v_mgs(nsx_handle *h, Span n, double *w, int dim, double *const *vs, int slot0);
 void v_axpy_multi(nsx_handle *h, Span n, double *x, int k, double *const *vs, const double *coef_host);
 void finalize_slots(nsx_handle *h, int slot0, int count);
 double read_scalar(nsx_handle *h, int slot);

@@ -100,9 +100,9 @@ static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b,
       // modified Gram-Schmidt, h(i) = vv . v_i after removing the previous components (add_and_dot chain)
       const bool consider = !re_orth && (inner % 5 == 4);
       if (consider) v_dot(h, n, vv, vv, S_NRM);
-      v_dot(h, n, vv, vec(0), S_H);
-      for (int i = 1; i < dim; ++i) v_add_and_dot(h, n, vv, -1.0, S_H + i - 1, vec(i - 1), vec(i), S_H + i);
-      v_add_and_dot(h, n, vv, -1.0, S_H + dim - 1, vec(dim - 1), vv, S_H + dim);
+      double *basis[N_TMP];
+      for (int i = 0; i < dim; ++i) basis[i] = vec(i);
+      v_mgs(h, n, vv, dim, basis, S_H);
       read_scalars(h, S_H, dim + 1, hh);
       double s = std::sqrt(hh[dim]);
       if (consider) {
@@ -110,9 +110,7 @@ static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b,
         if (!(s > 10. * norm_vv_start * std::sqrt(2.220446049250313e-16))) re_orth = true;
       }
       if (re_orth) {
-        v_dot(h, n, vv, vec(0), S_H2);
-        for (int i = 1; i < dim; ++i) v_add_and_dot(h, n, vv, -1.0, S_H2 + i - 1, vec(i - 1), vec(i), S_H2 + i);
-        v_add_and_dot(h, n, vv, -1.0, S_H2 + dim - 1, vec(dim - 1), vv, S_H2 + dim);
+        v_mgs(h, n, vv, dim, basis, S_H2);
         read_scalars(h, S_H2, dim + 1, h2);
         for (int i = 0; i < dim; ++i) hh[i] += h2[i];
         s = std::sqrt(h2[dim]);

@@ -13,13 +13,6 @@
 
 namespace nsx {
 
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
-  return __hiloint2double(hi, lo);
-}
 template <int LW>
 __device__ __forceinline__ double lane_group_sum(double v) {
   if (LW >= 2) v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
