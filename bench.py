@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 # scope name used by the library's HIP-event timer -> kernel symbol in rocprofv3 output
-KERNEL_OF = {"add_and_dot": "void nsx::k_reduce<1>", "dot": "void nsx::k_reduce<0>", "spmv_F": "void nsx::k_spmv_vel<3, 16, false>",
+KERNEL_OF = {"mgs_sweep": "nsx::k_mgs", "add_and_dot": "void nsx::k_reduce<1>", "dot": "void nsx::k_reduce<0>", "spmv_F": "void nsx::k_spmv_vel<3, 16, false>",
              "ilu_solve_F": "void nsx::k_ilu_solve_packed<3, 8, 8>", "ilu_solve_S": "void nsx::k_ilu_solve_packed<1, 32, 8>",
              "axpby": "nsx::k_axpby", "spmv_S": "void nsx::k_spmv_csr<32>"}
 
@@ -38,7 +38,7 @@ def pmc_traffic(scope):
     """HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same command (FETCH_SIZE and
     WRITE_SIZE in separate passes, values in KiB; gfx950 FETCH_SIZE counts 64 B per 128-B request, so it is doubled:
     /opt/skills/guides/MI355X_MICROARCH.md section HBM).  None when no profile is committed for the kernel."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_per_kernel.json")
+    path = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_per_kernel.json")  # tools/pmc_summary.py
     try:
         with open(path) as f:
             tab = json.load(f)
@@ -137,7 +137,9 @@ def cpu_baseline(level=2, ranks=16):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10,
+                    help="timed time steps (GMRES(28) needs a restart in some steps and not in others: 25 or 50 outer "
+                         "iterations; ten steps average over that)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--level", type=int, default=None, help="mesh level (default: 7 ~ 1.09M DoF per GPU)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")

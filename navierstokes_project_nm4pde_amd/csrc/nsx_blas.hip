@@ -258,9 +258,11 @@ __device__ __forceinline__ double mgs_block_sum(double v, double *sh) {
 
 __global__ __launch_bounds__(256) void k_mgs(int n, int split, int gap, double *__restrict__ w, MgsArgs V, int dim,
                                              unsigned long long *box, unsigned long long *box_next, int reset_wg, int reset_steps,
-                                             double *__restrict__ scal_out, int *err) {
+                                             double *__restrict__ scal_out, int *err, int normalize, double *pub_vals,
+                                             unsigned long long *pub_flag, unsigned long long seq) {
   __shared__ double sh[2][4];  // two buffers: a wave may start the next sum while a slower one still reads this one
   __shared__ unsigned long long bc;
+  __shared__ double tots[MGS_STEPS];
   const int nwg = gridDim.x, wg = blockIdx.x, T = nwg * 256, t = wg * 256 + threadIdx.x;
   unsigned long long *total = box + (size_t)MGS_STEPS * MGS_MAX_WG, *total_next = box_next + (size_t)MGS_STEPS * MGS_MAX_WG;
   // leave the other region empty for the next launch (stream order makes this visible to it): its last user filled
@@ -300,6 +302,7 @@ __global__ __launch_bounds__(256) void k_mgs(int n, int split, int gap, double *
       if (threadIdx.x == 0) {
         scal_out[s] = tot;
         __hip_atomic_store(total + s, mgs_bits(tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tots[s] = tot;
       }
     }
     if (threadIdx.x == 0) bc = mgs_wait(total + s, err);
@@ -312,7 +315,23 @@ __global__ __launch_bounds__(256) void k_mgs(int n, int split, int gap, double *
         wv[k] += alpha * vc[k];
         vc[k] = vn[k];
       }
+    } else if (normalize) {  // vv *= 1. / s with s = sqrt(|vv|^2), skipped for s == 0 (SolverGMRES)
+      const double nrm = sqrt(hs);
+      if (nrm != 0.0) {
+        const double inv = 1. / nrm;
+#pragma unroll
+        for (int k = 0; k < MGS_E; ++k) wv[k] = inv * wv[k];
+      }
     }
+  }
+  // hand the coefficients to the host: values, then the flag it is polling, both in fine-grained mapped host memory.  The
+  // stores are acknowledged (vmcnt) before the flag goes out; a system-scope release would also write back the whole L2.
+  if (wg == 0) {
+    __syncthreads();
+    if ((int)threadIdx.x <= dim) __hip_atomic_store(pub_vals + threadIdx.x, tots[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(pub_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 #pragma unroll
   for (int k = 0; k < MGS_E; ++k)
@@ -333,7 +352,21 @@ static void mgs_setup(nsx_handle *h) {
   h->mgs_max_wg = std::min(MGS_MAX_WG, per_cu * cus);
 }
 
-void v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int slot0) {
+static void wait_published(nsx_handle *h, unsigned long long seq) {
+  volatile unsigned long long *flag_host = (volatile unsigned long long *)(h->pub_host + N_SLOTS);
+  unsigned long long spins = 0;
+  while (__atomic_load_n(flag_host, __ATOMIC_ACQUIRE) != seq) {
+    if (++spins > 200000000ull) {  // bounded: fall back to a stream synchronisation, which also surfaces launch errors
+      HIP_CHECK(hipStreamSynchronize(h->stream));
+      if (__atomic_load_n(flag_host, __ATOMIC_ACQUIRE) != seq) NSX_THROW(NSX_ERR_HIP, "scalar publication never arrived");
+      break;
+    }
+  }
+  if (*(volatile int *)(h->pub_host + N_SLOTS + 2)) NSX_THROW(NSX_ERR_HIP, "Gram-Schmidt sweep: a workgroup waited more than 2 s for a partial sum");
+}
+
+// out[0..dim) = h(i), out[dim] = |w|^2 after the sweep.  Returns true when w was also normalised (only if asked to).
+bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int slot0, bool normalize, double *out) {
   const int n = sp.n;
   if (!h->comm) mgs_setup(h);
   const int nwg = std::max(1, std::min(h->mgs_max_wg, cdiv(n, 256 * 4)));
@@ -342,24 +375,32 @@ void v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
     v_dot(h, sp, w, vs[0], slot0);
     for (int i = 1; i < dim; ++i) v_add_and_dot(h, sp, w, -1.0, slot0 + i - 1, vs[i - 1], vs[i], slot0 + i);
     v_add_and_dot(h, sp, w, -1.0, slot0 + dim - 1, vs[dim - 1], w, slot0 + dim);
-    return;
+    read_scalars(h, slot0, dim + 1, out);
+    return false;
   }
-  LaunchScope ls(h, "mgs_sweep", 8.0 * n * (dim + 2));
-  MgsArgs V;
-  for (int i = 0; i < dim; ++i) V.v[i] = vs[i];
-  for (int i = dim; i < MGS_STEPS; ++i) V.v[i] = nullptr;
-  int n_ = n, split = sp.split, gap = sp.gap, dim_ = dim;
-  unsigned long long *box = h->mgs_box.p + (size_t)h->mgs_parity * MGS_REGION, *box_next = h->mgs_box.p + (size_t)(1 - h->mgs_parity) * MGS_REGION;
-  double *out = h->scal.p + slot0;
-  int *err = (int *)(h->pub_dev + N_SLOTS + 2);  // mapped host word, checked by read_scalars
-  int reset_wg = h->mgs_used_wg[1 - h->mgs_parity], reset_steps = h->mgs_used_steps[1 - h->mgs_parity];
-  void *args[] = {&n_, &split, &gap, &w, &V, &dim_, &box, &box_next, &reset_wg, &reset_steps, &out, &err};
-  HIP_CHECK(hipLaunchCooperativeKernel((const void *)k_mgs, dim3(nwg), dim3(256), args, 0, h->stream));
-  h->mgs_used_wg[h->mgs_parity] = nwg;
-  h->mgs_used_steps[h->mgs_parity] = dim + 1;
-  h->mgs_used_wg[1 - h->mgs_parity] = h->mgs_used_steps[1 - h->mgs_parity] = 0;
-  h->mgs_parity ^= 1;
-  for (int i = 0; i <= dim; ++i) h->slot_nb[slot0 + i] = 0;
+  const unsigned long long seq = ++h->pub_seq;
+  {
+    LaunchScope ls(h, "mgs_sweep", 8.0 * n * (dim + 2));
+    MgsArgs V;
+    for (int i = 0; i < dim; ++i) V.v[i] = vs[i];
+    for (int i = dim; i < MGS_STEPS; ++i) V.v[i] = nullptr;
+    int n_ = n, split = sp.split, gap = sp.gap, dim_ = dim, norm_ = normalize ? 1 : 0;
+    unsigned long long *box = h->mgs_box.p + (size_t)h->mgs_parity * MGS_REGION, *box_next = h->mgs_box.p + (size_t)(1 - h->mgs_parity) * MGS_REGION;
+    double *sout = h->scal.p + slot0, *pub_vals = h->pub_dev + slot0;
+    unsigned long long *pub_flag = (unsigned long long *)(h->pub_dev + N_SLOTS), seq_ = seq;
+    int *err = (int *)(h->pub_dev + N_SLOTS + 2);  // mapped host word, checked by wait_published
+    int reset_wg = h->mgs_used_wg[1 - h->mgs_parity], reset_steps = h->mgs_used_steps[1 - h->mgs_parity];
+    void *args[] = {&n_, &split, &gap, &w, &V, &dim_, &box, &box_next, &reset_wg, &reset_steps, &sout, &err, &norm_, &pub_vals, &pub_flag, &seq_};
+    HIP_CHECK(hipLaunchCooperativeKernel((const void *)k_mgs, dim3(nwg), dim3(256), args, 0, h->stream));
+    h->mgs_used_wg[h->mgs_parity] = nwg;
+    h->mgs_used_steps[h->mgs_parity] = dim + 1;
+    h->mgs_used_wg[1 - h->mgs_parity] = h->mgs_used_steps[1 - h->mgs_parity] = 0;
+    h->mgs_parity ^= 1;
+    for (int i = 0; i <= dim; ++i) h->slot_nb[slot0 + i] = 0;
+  }
+  wait_published(h, seq);
+  for (int i = 0; i <= dim; ++i) out[i] = h->pub_host[slot0 + i];
+  return normalize;
 }
 
 // ---- element-wise
@@ -478,20 +519,10 @@ void read_scalars(nsx_handle *h, int slot0, int count, double *out) {
   }
   const unsigned long long seq = ++h->pub_seq;
   unsigned long long *flag_dev = (unsigned long long *)(h->pub_dev + N_SLOTS);
-  volatile unsigned long long *flag_host = (volatile unsigned long long *)(h->pub_host + N_SLOTS);
   hipLaunchKernelGGL(k_publish, dim3(count), dim3(256), 0, h->stream, slot0, count, args, h->red_partial.p, h->scal.p, h->pub_dev, flag_dev, seq,
                      h->pub_counter.p);
-  // poll the sequence number (bounded: fall back to a stream synchronisation, which also surfaces launch errors)
-  unsigned long long spins = 0;
-  while (__atomic_load_n(flag_host, __ATOMIC_ACQUIRE) != seq) {
-    if (++spins > 200000000ull) {
-      HIP_CHECK(hipStreamSynchronize(h->stream));
-      if (__atomic_load_n(flag_host, __ATOMIC_ACQUIRE) != seq) NSX_THROW(NSX_ERR_HIP, "scalar publication never arrived");
-      break;
-    }
-  }
+  wait_published(h, seq);
   for (int i = 0; i < count; ++i) out[i] = h->pub_host[slot0 + i];
-  if (*(volatile int *)(h->pub_host + N_SLOTS + 2)) NSX_THROW(NSX_ERR_HIP, "Gram-Schmidt sweep: a workgroup waited more than 2 s for a partial sum");
 }
 void write_scalar(nsx_handle *h, int slot, double v) {
   HIP_CHECK(hipStreamSynchronize(h->stream));

@@ -281,6 +281,15 @@ __device__ __forceinline__ double dpp_f64(double v) {
   hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
+// same, but only the rows of 16 lanes selected by ROW_MASK receive a value; the other rows get 0 (used with the row
+// broadcasts 0x142 row_bcast:15 and 0x143 row_bcast:31, which hand the last lane of a row / of the lower half to the rows above)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64_rows(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
 
 // BLAS-1 (nsx_blas.hip): scalars live in h->scal[slot]
 void v_copy(nsx_handle *h, int n, double *d, const double *s);  // raw copy of n contiguous entries
@@ -294,8 +303,9 @@ void v_scale_vec(nsx_handle *h, int n, double *d, const double *f);
 void v_dot(nsx_handle *h, Span n, const double *a, const double *b, int slot);               // scal[slot] = a.b
 void v_add_and_dot(nsx_handle *h, Span n, double *d, double a, int aslot, const double *v, const double *w, int slot);
                                                                                             // d += a*scal[aslot]*v ; scal[slot] = d.w
-// modified Gram-Schmidt sweep of SolverGMRES (w against v_0..v_{dim-1}): scal[slot0+i] = h(i), scal[slot0+dim] = |w|^2 afterwards
-void v_mgs(nsx_handle *h, Span n, double *w, int dim, double *const *vs, int slot0);
+// modified Gram-Schmidt sweep of SolverGMRES (w against v_0..v_{dim-1}): out[i] = h(i), out[dim] = |w|^2 afterwards (host
+// values; scal[slot0+i] holds them too).  normalize: also w *= 1/|w| if the sweep runs as one launch; returns whether it did.
+bool v_mgs(nsx_handle *h, Span n, double *w, int dim, double *const *vs, int slot0, bool normalize, double *out);
 void v_axpy_multi(nsx_handle *h, Span n, double *x, int k, double *const *vs, const double *coef_host);
 void finalize_slots(nsx_handle *h, int slot0, int count);
 double read_scalar(nsx_handle *h, int slot);

@@ -229,7 +229,7 @@ void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> 
                 m |= xoff[g.colind[q]];
                 slot_of[q] = (int32_t)(base + lane);
               }
-              if (k == K - 1 && l < 4) m |= (xoff[step_rows[gi]] + 1) << 16;  // lanes 0..3 of the group: one per component
+              if (k == K - 1) m |= (xoff[step_rows[gi]] + 1) << 16;  // destination row, known to every lane of the group
             }
             meta[base + lane] = m;
           }

@@ -102,21 +102,20 @@ static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b,
       if (consider) v_dot(h, n, vv, vv, S_NRM);
       double *basis[N_TMP];
       for (int i = 0; i < dim; ++i) basis[i] = vec(i);
-      v_mgs(h, n, vv, dim, basis, S_H);
-      read_scalars(h, S_H, dim + 1, hh);
+      // the sweep can normalise vv itself (vv *= 1./s below) when no second sweep can follow it
+      bool normalized = v_mgs(h, n, vv, dim, basis, S_H, !re_orth && !consider, hh);
       double s = std::sqrt(hh[dim]);
       if (consider) {
         const double norm_vv_start = std::sqrt(read_scalar(h, S_NRM));
         if (!(s > 10. * norm_vv_start * std::sqrt(2.220446049250313e-16))) re_orth = true;
       }
       if (re_orth) {
-        v_mgs(h, n, vv, dim, basis, S_H2);
-        read_scalars(h, S_H2, dim + 1, h2);
+        normalized = v_mgs(h, n, vv, dim, basis, S_H2, true, h2);
         for (int i = 0; i < dim; ++i) hh[i] += h2[i];
         s = std::sqrt(h2[dim]);
       }
       hh[inner + 1] = s;
-      if (s != 0) v_scale(h, n, vv, 1. / s);
+      if (s != 0 && !normalized) v_scale(h, n, vv, 1. / s);
       // givens_rotation(h, gamma, ci, si, inner)
       for (int i = 0; i < inner; ++i) {
         const double sn = si[i], cs = ci[i], dummy = hh[i];

@@ -550,12 +550,19 @@ __device__ __forceinline__ void packed_slab(double v, int mk, double (&acc)[NCOM
   const bool last = (mk & 0x8000) != 0;  // last slab of the step (wave-uniform)
   const int dst = (mk >> 16) & 0xffff, l = lane % LW;
   constexpr bool MERGED = NCOMP > 1 && NCOMP <= 4 && LW >= 8;
+  constexpr bool SCALAR = NCOMP == 1 && LW >= 4;
+  // lane of the group that ends up with the sum in the one-component path: lane 0 up to 16 lanes per row (all lanes of
+  // a DPP row hold it), the first lane of the LAST row of the group beyond (the row broadcasts accumulate upwards)
+  constexpr int WL = LW <= 16 ? 0 : LW - 16;
   // the entry of x this lane will update is read FIRST: its LDS latency overlaps the gather + FMA + reduction chain
   double old = 0.0;
   int widx = 0;
-  const bool writer = last && dst && (MERGED ? l < NCOMP : l == 0);
+  const bool writer = last && dst && (MERGED ? l < NCOMP : (SCALAR ? l == WL : l == 0));
   if (MERGED) {
     widx = (dst - 1) * NCOMP + l;
+    if (writer) old = xs[widx];
+  } else if (SCALAR) {
+    widx = dst - 1;
     if (writer) old = xs[widx];
   }
   const double *xj = xs + (mk & 0x7fff) * NCOMP;
@@ -580,6 +587,15 @@ __device__ __forceinline__ void packed_slab(double v, int mk, double (&acc)[NCOM
       if (LW >= 32) w += __shfl_xor(w, 16, 64);
       if (LW >= 64) w += __shfl_xor(w, 32, 64);
       if (writer) xs[widx] = old - w;
+    } else if constexpr (SCALAR) {
+      double t = acc[0];
+      t += dpp_f64<0xB1>(t);
+      t += dpp_f64<0x4E>(t);
+      if (LW >= 8) t += dpp_f64<0x141>(t);   // row_half_mirror
+      if (LW >= 16) t += dpp_f64<0x140>(t);  // row_mirror: every lane of a 16-lane row holds the row's sum
+      if (LW >= 32) t += dpp_f64_rows<0x142, 0xA>(t);  // row_bcast:15 into rows 1 and 3: they now hold the sums of rows 0+1 / 2+3
+      if (LW >= 64) t += dpp_f64_rows<0x143, 0xC>(t);  // row_bcast:31 into rows 2 and 3: row 3 holds the wave's sum
+      if (writer) xs[widx] = old - t;
     } else {
 #pragma unroll
       for (int c = 0; c < NCOMP; ++c) acc[c] = lane_group_sum<LW>(acc[c]);

@@ -50,9 +50,10 @@ else:
         print("PF", os.environ.get("NSX_PF"), "blocks", nsub, ssub, {k: round(v["total_ms"] / v["launches"] * 1e3, 1) for k, v in tab.items()}, flush=True)
         sys.exit(0)
     tm = 0.0
-    for step in range(1, 7):
+    nsteps = int(os.environ.get("NSX_PROBE_STEPS", "6"))
+    for step in range(1, nsteps + 1):
         tm += 2e-4
-        if step == 4:
+        if step == 4 and nsteps <= 6:
             dev.profile(True)
         t0 = time.time()
         if step == 1: dev.assemble(nsx.TEMAM)
