@@ -350,6 +350,7 @@ static void mgs_setup(nsx_handle *h) {
   h->mgs_box.alloc(2 * MGS_REGION);
   HIP_CHECK(hipMemsetAsync(h->mgs_box.p, 0xff, 2 * MGS_REGION * sizeof(unsigned long long), h->stream));
   h->mgs_max_wg = std::min(MGS_MAX_WG, per_cu * cus);
+  if (getenv("NSX_DEBUG")) fprintf(stderr, "[nsx] mgs sweep: %d CUs x %d resident workgroups, grid <= %d\n", cus, per_cu, h->mgs_max_wg);
 }
 
 static void wait_published(nsx_handle *h, unsigned long long seq) {
@@ -391,7 +392,13 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
     int *err = (int *)(h->pub_dev + N_SLOTS + 2);  // mapped host word, checked by wait_published
     int reset_wg = h->mgs_used_wg[1 - h->mgs_parity], reset_steps = h->mgs_used_steps[1 - h->mgs_parity];
     void *args[] = {&n_, &split, &gap, &w, &V, &dim_, &box, &box_next, &reset_wg, &reset_steps, &sout, &err, &norm_, &pub_vals, &pub_flag, &seq_};
-    HIP_CHECK(hipLaunchCooperativeKernel((const void *)k_mgs, dim3(nwg), dim3(256), args, 0, h->stream));
+    // Co-residency: the grid never exceeds what the device holds at once (mgs_setup), the stream is in-order and nothing else
+    // runs on this queue, so a plain launch places every workgroup at once; hipLaunchCooperativeKernel guarantees it but
+    // goes through the device-wide cooperative queue, which costs ~20 us of cross-queue synchronisation per launch.
+    // Should a workgroup ever be missing, the bounded waits end the kernel after 2 s and the solve fails loudly.
+    static const bool coop = getenv("NSX_MGS_COOP") && atoi(getenv("NSX_MGS_COOP")) != 0;
+    if (coop) HIP_CHECK(hipLaunchCooperativeKernel((const void *)k_mgs, dim3(nwg), dim3(256), args, 0, h->stream));
+    else HIP_CHECK(hipLaunchKernel((const void *)k_mgs, dim3(nwg), dim3(256), args, 0, h->stream));
     h->mgs_used_wg[h->mgs_parity] = nwg;
     h->mgs_used_steps[h->mgs_parity] = dim + 1;
     h->mgs_used_wg[1 - h->mgs_parity] = h->mgs_used_steps[1 - h->mgs_parity] = 0;
