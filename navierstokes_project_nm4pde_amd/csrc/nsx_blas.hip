@@ -168,14 +168,14 @@ void finalize_slots(nsx_handle *h, int slot0, int count) {
   for (int i = 0; i < count; ++i) h->slot_nb[slot0 + i] = 0;
 }
 
-static void after_reduction(nsx_handle *h, int slot, int nb) {
+void after_reduction(nsx_handle *h, int slot, int nb) {
   h->slot_nb[slot] = nb > 1 ? nb : 0;
   if (h->comm) {  // global sum needed before anybody consumes the value
     finalize_slots(h, slot, 1);
     comm_allreduce_scalars(h, slot, 1);
   }
 }
-static double *red_out(nsx_handle *h, int slot, int nb) {
+double *red_out(nsx_handle *h, int slot, int nb) {
   return nb > 1 ? h->red_partial.p + (size_t)slot * RED_STRIDE : h->scal.p + slot;
 }
 

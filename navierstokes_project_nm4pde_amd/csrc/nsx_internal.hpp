@@ -258,8 +258,9 @@ void spmv_B(nsx_handle *h, const double *xu, double *yp);                       
 void spmv_S(nsx_handle *h, const double *x, double *y);                                     // y = negative_S x
 void schur_numeric(nsx_handle *h, const double *w);                                         // S = B diag(w) G
 void ilu_factor(nsx_handle *h, const DevCsr &g, IluSchedule &s, const double *vals, double *lu, const char *name);
-void ilu_solve(nsx_handle *h, const DevCsr &g, const IluSchedule &s, const double *lu, const double *b, double *x, int ncomp,
-               const char *name);
+// dot_slot >= 0: also leave b.x in that scalar slot when the packed kernel can do it; returns whether it did
+bool ilu_solve(nsx_handle *h, const DevCsr &g, const IluSchedule &s, const double *lu, const double *b, double *x, int ncomp,
+               const char *name, int dot_slot = -1);
 void extract_diag(nsx_handle *h, const DevCsr &g, const double *vals, double *d);           // scalar diag
 void abs_rowsum(nsx_handle *h, const DevCsr &g, const double *vals, double *d);
 
@@ -308,6 +309,10 @@ void v_add_and_dot(nsx_handle *h, Span n, double *d, double a, int aslot, const 
 bool v_mgs(nsx_handle *h, Span n, double *w, int dim, double *const *vs, int slot0, bool normalize, double *out);
 void v_axpy_multi(nsx_handle *h, Span n, double *x, int k, double *const *vs, const double *coef_host);
 void finalize_slots(nsx_handle *h, int slot0, int count);
+// for kernels that leave nb <= 512 per-workgroup partial sums of a scalar themselves: where to put them, and the
+// bookkeeping (and the all-reduce of a distributed run) once the kernel is launched
+double *red_out(nsx_handle *h, int slot, int nb);
+void after_reduction(nsx_handle *h, int slot, int nb);
 double read_scalar(nsx_handle *h, int slot);
 void read_scalars(nsx_handle *h, int slot0, int count, double *out);
 void write_scalar(nsx_handle *h, int slot, double v);

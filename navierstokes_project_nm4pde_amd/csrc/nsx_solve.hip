@@ -37,6 +37,7 @@ struct Tmp {
     if (!b) {
       b = new DevBuf<double>();
       b->alloc(n);
+      b->zero(h->stream);  // never hand out uninitialised memory (ghost entries are only written by halo exchanges)
     }
   }
   ~Tmp() { h->pool.push_back(b); }
@@ -64,13 +65,17 @@ constexpr int N_TMP = 30;  // SolverGMRES::AdditionalData::max_n_tmp_vectors
 enum { S_H = 8 /* 8..8+N_TMP */, S_NRM = 40, S_H2 = 41 /* re-orthogonalisation coefficients 41..41+N_TMP */, S_GH = 2, S_DH = 3, S_RES = 4, S_GH2 = 5, S_T = 6 };
 
 // SolverGMRES<VectorType>::solve (left preconditioning, default residual).
-static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b, const Op &P, Span n, int len, double tol, int maxiter) {
+// zero_new: a freshly created Epetra vector is zero.  That only matters when the preconditioner READS its destination
+// (aSIMPLE takes it as the initial guess of its inner solve, Prec.hpp:271), i.e. for the outer solve; the inner solves'
+// operators (SpMV, ILU) overwrite every owned entry, so their temporaries are handed out as they come from the pool.
+static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b, const Op &P, Span n, int len, double tol, int maxiter,
+                         bool zero_new = false) {
   SolveResult res{1, 0, 0.0};
   std::vector<std::unique_ptr<Tmp>> tmp(N_TMP);
   auto vec = [&](int i) -> double * {
     if (!tmp[i]) {
       tmp[i] = std::make_unique<Tmp>(h, len);
-      v_zero(h, len, tmp[i]->p());  // a freshly created Epetra vector is zero
+      if (zero_new) v_zero(h, len, tmp[i]->p());
     }
     return tmp[i]->p();
   };
@@ -149,7 +154,15 @@ static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b,
 }
 
 // SolverCG<VectorType>::solve with a preconditioner.
-static SolveResult cg(nsx_handle *h, const Op &A, double *x, const double *b, const Op &P, Span n, int len, double tol, int maxiter) {
+// Pdot (optional): dst = P src AND scal[slot] = src . dst in the same launch; returns false if it only applied P.
+using OpDot = std::function<bool(double *dst, const double *src, int slot)>;
+static SolveResult cg(nsx_handle *h, const Op &A, double *x, const double *b, const Op &P, Span n, int len, double tol, int maxiter,
+                      const OpDot *Pdot = nullptr) {
+  auto apply_P_dot = [&](double *dst, const double *src, int slot) {  // h = P g ; slot = g . h
+    if (Pdot && (*Pdot)(dst, src, slot)) return;
+    if (!Pdot) P(dst, src);
+    v_dot(h, n, src, dst, slot);
+  };
   SolveResult res{1, 0, 0.0};
   Tmp g(h, len), d(h, len), hv(h, len);
   int it = 0;
@@ -161,11 +174,10 @@ static SolveResult cg(nsx_handle *h, const Op &A, double *x, const double *b, co
   res.last = r;
   int conv = sc_check(0, r, tol, maxiter);
   if (conv == 0) {
-    P(hv.p(), g.p());
+    int gh = S_GH, gh_new = S_GH2;  // ping-pong slots for (g.h) of the current / next iteration
+    apply_P_dot(hv.p(), g.p(), gh);
     v_copy(h, n.n, d.p(), hv.p());
     v_scale(h, n, d.p(), -1.);
-    int gh = S_GH, gh_new = S_GH2;  // ping-pong slots for (g.h) of the current / next iteration
-    v_dot(h, n, g.p(), hv.p(), gh);
     while (conv == 0) {
       it++;
       A(hv.p(), d.p());
@@ -175,8 +187,7 @@ static SolveResult cg(nsx_handle *h, const Op &A, double *x, const double *b, co
       res.last = r;
       conv = sc_check(it, r, tol, maxiter);
       if (conv != 0) break;
-      P(hv.p(), g.p());
-      v_dot(h, n, g.p(), hv.p(), gh_new);
+      apply_P_dot(hv.p(), g.p(), gh_new);
       cg_direction(h, n.n, d.p(), hv.p(), gh_new, gh);  // beta = gh_new / gh_old ; d = beta d - h
       std::swap(gh, gh_new);
     }
@@ -245,6 +256,7 @@ void prec_vmult(nsx_handle *h, int type, double tol, int maxit, double *dst, con
   Op Sm = [h](double *d, const double *s) { spmv_S(h, s, d); };
   Op PF = [h, dim](double *d, const double *s) { ilu_solve(h, h->gA, h->schedF, h->luF.p, s, d, dim, "ilu_solve_F"); };
   Op PS = [h](double *d, const double *s) { ilu_solve(h, h->gS, h->schedS, h->luS.p, s, d, 1, "ilu_solve_S"); };
+  OpDot PSdot = [h](double *d, const double *s, int slot) { return ilu_solve(h, h->gS, h->schedS, h->luS.p, s, d, 1, "ilu_solve_S", slot); };
 
   if (type == NSX_PREC_YOSIDA) {  // Prec.hpp:365-408
     Tmp yu(h, len_u), yp(h, len_p), tmp(h, len_p), tmp2(h, len_u), res(h, len_u);
@@ -253,7 +265,7 @@ void prec_vmult(nsx_handle *h, int type, double tol, int maxit, double *dst, con
     count(st, true, gmres(h, Fm, yu.p(), src_u, PF, n_u, len_u, tol * norm2(h, n_u, src_u), maxit)); // :371-382
     spmv_B(h, yu.p(), tmp.p());                                                               // :385
     v_add(h, n_p, tmp.p(), -1.0, src_p);                                                      // :386
-    count(st, false, cg(h, Sm, yp.p(), tmp.p(), PS, n_p, len_p, tol * norm2(h, n_p, tmp.p()), maxit));  // :388-390
+    count(st, false, cg(h, Sm, yp.p(), tmp.p(), PS, n_p, len_p, tol * norm2(h, n_p, tmp.p()), maxit, &PSdot));  // :388-390
     v_copy(h, n_p, dst_p, yp.p());                                                            // :394
     spmv_G(h, dst_p, tmp2.p(), false);                                                        // :398
     v_zero(h, n_u, res.p());                                                                  // :401
@@ -267,7 +279,7 @@ void prec_vmult(nsx_handle *h, int type, double tol, int maxit, double *dst, con
     count(st, true, gmres(h, Fm, sol1_u.p(), src_u, PF, n_u, len_u, tol * norm2(h, n_u, src_u), maxit));  // :157-173
     spmv_B(h, sol1_u.p(), temp_1.p());                                                             // :175
     v_add(h, n_p, temp_1.p(), -1.0, src_p);                                                        // :176
-    count(st, false, cg(h, Sm, sol1_p.p(), temp_1.p(), PS, n_p, len_p, tol * norm2(h, n_p, temp_1.p()), maxit));  // :179-182
+    count(st, false, cg(h, Sm, sol1_p.p(), temp_1.p(), PS, n_p, len_p, tol * norm2(h, n_p, temp_1.p()), maxit, &PSdot));  // :179-182
     v_copy(h, n_p, dst_p, sol1_p.p());                                                             // :194
     v_scale(h, n_p, dst_p, 1. / 0.5);                                                              // :195, alpha = 0.5 (:207)
     v_copy(h, n_u, dst_u, sol1_u.p());                                                             // :199
@@ -294,7 +306,7 @@ void prec_vmult(nsx_handle *h, int type, double tol, int maxit, double *dst, con
     v_copy(h, n_u, yu.p(), tmp.p());                  // :493
     spmv_B(h, tmp.p(), tmp2.p());                     // :496
     v_sadd(h, n_p, yp.p(), -1.0, 1.0, tmp2.p());      // :497
-    count(st, false, cg(h, Sm, dst_p, yp.p(), PS, n_p, len_p, tol * norm2(h, n_p, yp.p()), maxit));  // :500-502
+    count(st, false, cg(h, Sm, dst_p, yp.p(), PS, n_p, len_p, tol * norm2(h, n_p, yp.p()), maxit, &PSdot));  // :500-502
     v_copy(h, n_p, yp.p(), dst_p);                    // :504
     spmv_F(h, h->vF.p, yu.p(), t.p());                // :507 F->vmult(yu,yu): Epetra multiplies out of place when the arguments alias
     v_copy(h, n_u, yu.p(), t.p());
@@ -322,7 +334,7 @@ void solve_time_step(nsx_handle *h, int type, double tol, double inner_rtol, int
   t0 = now_s();
   Op A = [h](double *d, const double *s) { spmv_saddle(h, s, d); };
   Op P = [h, type, inner_rtol, inner_maxiter, st](double *d, const double *s) { prec_vmult(h, type, inner_rtol, inner_maxiter, d, s, st); };
-  SolveResult r = gmres(h, A, h->sol_owned.p, h->rhs.p, P, n, h->len_blk, tol, maxiter);  // NS3D.cpp:574
+  SolveResult r = gmres(h, A, h->sol_owned.p, h->rhs.p, P, n, h->len_blk, tol, maxiter, true);  // NS3D.cpp:574
   v_copy(h, h->len_blk, h->sol.p, h->sol_owned.p);  // solution = solution_owned (NS3D.cpp:638): copy + ghost import
   comm_halo_u(h, h->sol.p);
   comm_halo_p(h, h->sol.p + h->off_p);

@@ -645,7 +645,7 @@ template <int NCOMP, int LW, int PF>
 __global__ __launch_bounds__(64) void k_ilu_solve_packed(int bpw, const int32_t *__restrict__ wave_blk, const int32_t *__restrict__ bptr,
                                                          const int32_t *__restrict__ slab_ptr, const int32_t *__restrict__ meta,
                                                          const double *__restrict__ val, const double *__restrict__ dinv,
-                                                         const double *__restrict__ b, double *__restrict__ x) {
+                                                         const double *b, double *x, double *__restrict__ dot_partial) {
   extern __shared__ double xs[];
   const int w = blockIdx.x, lane = threadIdx.x;
   const int s0 = slab_ptr[2 * w], s1 = slab_ptr[2 * w + 1], s2 = slab_ptr[2 * w + 2];
@@ -669,22 +669,31 @@ __global__ __launch_bounds__(64) void k_ilu_solve_packed(int bpw, const int32_t 
     xo += nloc;
   }
   packed_sweep<NCOMP, LW, PF>(s1, s2, meta, val, xs, lane);  // x = U^{-1} y
+  double dot = 0.0;  // b . x over this wave's rows (CG's g.h right after the preconditioner, Prec.hpp:388 / SolverCG)
   for (int p = 0, xo = 0; p < bpw; ++p) {
     const int blk = wave_blk[w * bpw + p];
     if (blk < 0) continue;
     const int r0 = bptr[blk], nloc = bptr[blk + 1] - r0;
-    for (int t = lane; t < nloc * NCOMP; t += 64) x[(size_t)r0 * NCOMP + t] = xs[xo * NCOMP + t];
+    for (int t = lane; t < nloc * NCOMP; t += 64) {
+      const double v = xs[xo * NCOMP + t];
+      if (dot_partial) dot += b[(size_t)r0 * NCOMP + t] * v;
+      x[(size_t)r0 * NCOMP + t] = v;
+    }
     xo += nloc;
+  }
+  if (dot_partial) {
+    dot = lane_group_sum<64>(dot);
+    if (lane == 0) dot_partial[w] = dot;
   }
 }
 
 template <int NCOMP, int LW>
-static void launch_packed(nsx_handle *h, const IluSchedule &s, const double *b, double *x) {
+static void launch_packed(nsx_handle *h, const IluSchedule &s, const double *b, double *x, double *dot_partial) {
   const size_t shm = (size_t)s.max_wave_rows * NCOMP * sizeof(double);
   static const int pf = getenv("NSX_PF") ? atoi(getenv("NSX_PF")) : 8;
 #define NSX_GO(PF_)                                                                                                               \
   hipLaunchKernelGGL((k_ilu_solve_packed<NCOMP, LW, PF_>), dim3(s.n_waves), dim3(64), shm, h->stream, s.blocks_per_wave, s.pk_wave_blk.p, \
-                     s.block_ptr.p, s.pk_slab_ptr.p, s.pk_meta.p, s.pk_val.p, s.pk_dinv.p, b, x)
+                     s.block_ptr.p, s.pk_slab_ptr.p, s.pk_meta.p, s.pk_val.p, s.pk_dinv.p, b, x, dot_partial)
   if (pf == 4) NSX_GO(4); else if (pf == 16) NSX_GO(16); else NSX_GO(8);
 #undef NSX_GO
 }
@@ -702,26 +711,32 @@ static void launch_ilu_solve(nsx_handle *h, const DevCsr &g, const IluSchedule &
 #undef NSX_ILU_ARGS
 }
 
-void ilu_solve(nsx_handle *h, const DevCsr &g, const IluSchedule &s, const double *lu, const double *b, double *x, int ncomp,
-               const char *name) {
+bool ilu_solve(nsx_handle *h, const DevCsr &g, const IluSchedule &s, const double *lu, const double *b, double *x, int ncomp,
+               const char *name, int dot_slot) {
   const bool packed = s.packed_ok && (size_t)s.max_wave_rows * ncomp * sizeof(double) <= 64 * 1024;
   // algorithmic bytes: the CSR factor once (12 B/entry) + rhs/solution vectors; the packed stream moves 768 B per slab
   LaunchScope ls(h, name, 12.0 * g.nnz() + (double)g.n_rows() * (4 + 16.0 * ncomp));
   if (packed) {
     const int lw = s.lanes_per_row;
-#define NSX_PK(NC)                                              \
-    if (lw == 8) return launch_packed<NC, 8>(h, s, b, x);       \
-    if (lw == 16) return launch_packed<NC, 16>(h, s, b, x);     \
-    if (lw == 32) return launch_packed<NC, 32>(h, s, b, x);       \
-    if (lw == 64) return launch_packed<NC, 64>(h, s, b, x);
+    const bool with_dot = dot_slot >= 0 && s.n_waves >= 2 && s.n_waves <= 512;  // one partial sum per wave
+    double *dp = with_dot ? red_out(h, dot_slot, s.n_waves) : nullptr;
+#define NSX_PK(NC)                                                    \
+    if (lw == 8) launch_packed<NC, 8>(h, s, b, x, dp);                \
+    else if (lw == 16) launch_packed<NC, 16>(h, s, b, x, dp);         \
+    else if (lw == 32) launch_packed<NC, 32>(h, s, b, x, dp);         \
+    else if (lw == 64) launch_packed<NC, 64>(h, s, b, x, dp);         \
+    else NSX_THROW(NSX_ERR_ARG, "internal: lanes per row %d", lw);
     if (ncomp == 1) { NSX_PK(1) }
-    if (ncomp == 2) { NSX_PK(2) }
-    if (ncomp == 3) { NSX_PK(3) }
+    else if (ncomp == 2) { NSX_PK(2) }
+    else { NSX_PK(3) }
 #undef NSX_PK
+    if (with_dot) after_reduction(h, dot_slot, s.n_waves);
+    return with_dot;
   }
   if (ncomp == 1) launch_ilu_solve<1>(h, g, s, lu, b, x);
   else if (ncomp == 2) launch_ilu_solve<2>(h, g, s, lu, b, x);
   else launch_ilu_solve<3>(h, g, s, lu, b, x);
+  return false;
 }
 
 }  // namespace nsx
