@@ -147,6 +147,20 @@ const double *nsxh_tables_dN1(const nsxh_tables *);      /* [n_q][n_p1][dim] */
 /* face rule only: n_q = n_faces * n_qf; face f uses points [f*n_qf, (f+1)*n_qf) */
 int nsxh_tables_n_qf(const nsxh_tables *);
 
+/* ---- post-processing (pure host I/O, the reference's output side) ---- */
+
+/* NavierStokes::output (reference NavierStokes3D.cpp:643-683, NavierStokes2D.cpp:642-677): DataOut with the vector
+ * "velocity", the scalar "pressure" and the cell-wise "partitioning", build_patches() with one subdivision (one linear
+ * patch per cell with its own vertices), write_vtu_with_pvtu_record(directory, basename, counter, comm, -, 1).
+ * Writes <directory>/<basename>_<counter>.0.vtu and <directory>/<basename>_<counter>.pvtu (ASCII data arrays; the
+ * directory is created if missing).  solution = ghosted solution in the global dof numbering.  0 on success. */
+int nsxh_write_vtu(const nsxh_dofs *, const double *solution, const char *directory, const char *basename, unsigned counter);
+
+/* NavierStokes::compute_pressure_difference (reference NavierStokes3D.cpp:849-923): P1 pressure at two points
+ * (VectorTools::point_value): p(a) - p(b).  A point outside the mesh contributes 0 like a rank that does not hold it.
+ * Returns the number of points found (0..2). */
+int nsxh_pressure_difference(const nsxh_dofs *, const double *solution, const double *point_a, const double *point_b, double *diff);
+
 #ifdef __cplusplus
 }
 #endif

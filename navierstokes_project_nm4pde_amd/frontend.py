@@ -39,6 +39,8 @@ def _lib():
         "nsxh_distribute_dofs": (vp, [vp]),
         "nsxh_distribute_dofs_ordered": (vp, [vp, C.c_int]),
         "nsxh_n_colours": (C.c_int, [vp]),
+        "nsxh_write_vtu": (C.c_int, [vp, C.POINTER(C.c_double), C.c_char_p, C.c_char_p, C.c_uint]),
+        "nsxh_pressure_difference": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "nsxh_dofs_free": (None, [vp]),
         "nsxh_dofs_per_cell": (C.c_int, [vp]),
         "nsxh_n_nodes_p2": (C.c_int, [vp]),
@@ -176,6 +178,22 @@ class DoFs:
         self.pnode_owner = _arr(L.nsxh_pnode_owner(h), (self.n_nodes_p1,), np.int32)
         self.owned_u_ptr = _arr(L.nsxh_owned_u_ptr(h), (self.n_subdomains + 1,), np.int32)
         self.owned_p_ptr = _arr(L.nsxh_owned_p_ptr(h), (self.n_subdomains + 1,), np.int32)
+
+    def write_vtu(self, solution, directory, basename, counter):
+        """NavierStokes::output: <directory>/<basename>_<counter>.0.vtu + .pvtu (reference NavierStokes3D.cpp:643-683)."""
+        x = np.ascontiguousarray(solution, dtype=np.float64)
+        assert x.shape == (self.n_dofs,)
+        if self._lib.nsxh_write_vtu(self._h, x.ctypes.data_as(C.POINTER(C.c_double)), str(directory).encode(), basename.encode(), int(counter)):
+            raise OSError("nsxh_write_vtu failed for %s" % directory)
+
+    def pressure_difference(self, solution, point_a, point_b):
+        """NavierStokes::compute_pressure_difference (reference NavierStokes3D.cpp:849-923): (p(a) - p(b), points found)."""
+        x = np.ascontiguousarray(solution, dtype=np.float64)
+        a, b = (np.ascontiguousarray(p, dtype=np.float64) for p in (point_a, point_b))
+        out = C.c_double(0.0)
+        dp = C.POINTER(C.c_double)
+        n = self._lib.nsxh_pressure_difference(self._h, x.ctypes.data_as(dp), a.ctypes.data_as(dp), b.ctypes.data_as(dp), C.byref(out))
+        return out.value, n
 
     def boundary_dofs(self, boundary_id):
         p = _i32p()

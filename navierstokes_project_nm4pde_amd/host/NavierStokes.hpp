@@ -75,7 +75,10 @@ public:
   }
 
   std::vector<double> time_prec, time_solve;  // NavierStokes3D.hpp:121-122
+  std::vector<double> vec_drag, vec_lift, vec_drag_coeff, vec_lift_coeff;  // NavierStokes3D.hpp:116-119 (never filled there)
   std::vector<int> gmres_iterations;
+  bool write_output = true;   // output(): VTU + PVTU record every 20 steps (3D) / every step (2D), like the reference
+  bool write_csv = true;      // 2D: gmres.csv and coeff_2.csv appended per step (NavierStokes2D.cpp:623-636,679-692)
   unsigned int preconditioner_type = dim == 3 ? 0 : 3;  // NavierStokes3D.cpp:562 / NavierStokes2D.cpp:547
   double nu = 1e-3;                                     // NavierStokes3D.hpp:162
   bool verbose = true;
@@ -114,6 +117,7 @@ public:
     out() << "===============================================" << std::endl << "Applying the initial condition" << std::endl;
     std::vector<double> u0((size_t)n_u + n_p, 0.0);  // u_0 = ZeroFunction (NavierStokes3D.hpp:200)
     ck(nsx_set_solution(h, u0.data()));
+    output(0, {0.0, 0.0});  // NavierStokes3D.cpp:699, NavierStokes2D.cpp:712
     unsigned int time_step = 0;
     double time = 0;
     while (time < T - 0.5 * deltat) {
@@ -124,12 +128,17 @@ public:
       if (time == deltat) assemble(time);
       else assemble_time_step(time);
       solve_time_step();
+      current_time = time;
+      // NavierStokes3D.cpp:725-726: `time == T - deltat` in floating point; compared to half a step here
+      if (dim == 3 && std::fabs(time - (T - deltat)) < 0.5 * deltat) compute_pressure_difference();
       // NavierStokes3D.cpp:728-733 (forces only after t = 0.1); NavierStokes2D.cpp:737-741 (every step)
+      std::vector<double> coefficients = {0.0, 0.0};
       if (dim == 2 || time > 0.1) {
-        const std::vector<double> coefficients = compute_forces();
+        coefficients = compute_forces();
         c_D_max = std::max(coefficients[0], c_D_max);
         c_L_min = std::min(coefficients[1], c_L_min);
       }
+      if (time_step % (dim == 3 ? 20 : 1) == 0) output(time_step, coefficients);  // NavierStokes3D.cpp:734, NavierStokes2D.cpp:743
     }
     out() << "===============================================" << std::endl
           << "Drag Coefficient Max ----->   " << c_D_max << std::endl
@@ -149,7 +158,39 @@ public:
     const double den = dim == 3 ? rho * mean_v * mean_v * D * H : mean_v * mean_v * D;
     const double c_d = (2. * drag) / den, c_l = (2. * lift) / den;
     out() << "Coeff:\t " << c_d << " Coeff:\t " << c_l << std::endl;
+    vec_drag.push_back(drag);
+    vec_lift.push_back(lift);
+    vec_drag_coeff.push_back(c_d);
+    vec_lift_coeff.push_back(c_l);
     return {c_d, c_l};
+  }
+
+  // NavierStokes::output (NavierStokes3D.cpp:643-683; NavierStokes2D.cpp:642-695 also appends the coefficients to coeff_2.csv)
+  void output(const unsigned int &time_step, const std::vector<double> &coeff = {0.0, 0.0}) const {
+    if (write_output) {
+      out() << "===============================================" << std::endl;
+      const std::string output_file_name = dim == 3 ? "output-navier-stokes-3D" : "output-navier-stokes-2D";
+      const std::vector<double> x = get_solution();
+      if (nsxh_write_vtu(dofs, x.data(), dim == 3 ? "./outputConvergence/" : "./output2D_1/", output_file_name.c_str(), time_step))
+        throw std::runtime_error("cannot write " + output_file_name);
+      out() << "Output written to " << output_file_name << std::endl;
+    }
+    if (dim == 2 && write_csv) {
+      std::ofstream coeff_file("coeff_2.csv", std::ios::app);
+      if (coeff_file.is_open()) coeff_file << time_step << "," << coeff[0] << "," << coeff[1] << "\n";
+      else out() << "Error: Unable to open coeff.csv for writing." << std::endl;
+    }
+    if (write_output) out() << "===============================================" << std::endl;
+  }
+
+  // NavierStokes::compute_pressure_difference (NavierStokes3D.cpp:849-923)
+  double compute_pressure_difference() const {
+    const double p_a[3] = {0.45, 0.2, 0.205}, p_e[3] = {0.55, 0.2, 0.205};
+    const std::vector<double> x = get_solution();
+    double p_diff = 0.0;
+    nsxh_pressure_difference(dofs, x.data(), p_a, p_e, &p_diff);
+    out() << "Pressure difference (P(A) - P(B)) = " << p_diff << std::endl;
+    return p_diff;
   }
   double c_D_max = -999, c_L_min = 999;
 
@@ -203,6 +244,12 @@ protected:
     time_solve.push_back(st.t_solve);
     gmres_iterations.push_back(st.outer_iterations);
     out() << "Result:  " << st.outer_iterations << " GMRES iterations" << std::endl;
+    if (dim == 2 && write_csv) {  // NavierStokes2D.cpp:622-636
+      const int Re = int(0.1 * 1.5 * std::sin(inlet_velocity.get_time() * M_PI / 8.0) / .001);
+      std::ofstream coeff_file("gmres.csv", std::ios::app);
+      if (coeff_file.is_open()) coeff_file << inlet_velocity.get_time() << ',' << Re << ',' << st.outer_iterations << "\n";
+      else out() << "Error: Unable to open coeff.csv for writing." << std::endl;
+    }
   }
 
   void setup_force_faces() {  // faces with boundary id 3 and the face-quadrature tables (FEFaceValues of compute_forces)
@@ -253,6 +300,7 @@ protected:
   nsxh_dofs *dofs = nullptr;
   nsx_handle *h = nullptr;
   int n_u = 0, n_p = 0;
+  double current_time = 0.0;
 };
 
 }  // namespace nsx

@@ -15,12 +15,15 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <iomanip>
 #include <map>
 #include <numeric>
 #include <sstream>
 #include <string>
 #include <unordered_map>
 #include <vector>
+
+#include <sys/stat.h>
 
 #include "graph.hpp"
 
@@ -1162,5 +1165,109 @@ const int32_t *nsxh_rank_view_send_u_ptr(const nsxh_rank_view *v) { return v->se
 const int32_t *nsxh_rank_view_send_u_nodes(const nsxh_rank_view *v) { return v->send_u_nodes.data(); }
 const int32_t *nsxh_rank_view_send_p_ptr(const nsxh_rank_view *v) { return v->send_p_ptr.data(); }
 const int32_t *nsxh_rank_view_send_p_nodes(const nsxh_rank_view *v) { return v->send_p_nodes.data(); }
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ post-processing (N4: output side of the reference)
+extern "C" {
+
+int nsxh_write_vtu(const nsxh_dofs *d, const double *solution, const char *directory, const char *basename, unsigned counter) {
+  if (!d || !solution || !directory || !basename) return -1;
+  const int dim = d->dim, nv = dim + 1, nc = d->n_cells;
+  std::string dir(directory);
+  if (!dir.empty() && dir.back() != '/') dir += '/';
+  for (size_t pos = 1; pos < dir.size(); ++pos)  // mkdir -p
+    if (dir[pos] == '/') ::mkdir(dir.substr(0, pos).c_str(), 0777);
+  const std::string stem = std::string(basename) + "_" + std::to_string(counter);
+  const std::string piece = stem + ".0.vtu";
+  std::ofstream f(dir + piece);
+  if (!f) return -1;
+  f << std::setprecision(17);
+  const int32_t *sub = d->mesh->subdomain.empty() ? nullptr : d->mesh->subdomain.data();
+  f << "<?xml version=\"1.0\"?>\n<VTKFile type=\"UnstructuredGrid\" version=\"0.1\" byte_order=\"LittleEndian\">\n<UnstructuredGrid>\n"
+    << "<Piece NumberOfPoints=\"" << (int64_t)nc * nv << "\" NumberOfCells=\"" << nc << "\">\n";
+  f << "<Points>\n<DataArray type=\"Float64\" NumberOfComponents=\"3\" format=\"ascii\">\n";
+  for (int c = 0; c < nc; ++c)
+    for (int v = 0; v < nv; ++v) {
+      const double *x = d->cell_coords.data() + ((size_t)c * nv + v) * dim;
+      f << x[0] << ' ' << x[1] << ' ' << (dim == 3 ? x[2] : 0.0) << '\n';
+    }
+  f << "</DataArray>\n</Points>\n<Cells>\n<DataArray type=\"Int32\" Name=\"connectivity\" format=\"ascii\">\n";
+  for (int64_t k = 0; k < (int64_t)nc * nv; ++k) f << k << ((k + 1) % nv ? ' ' : '\n');
+  f << "</DataArray>\n<DataArray type=\"Int32\" Name=\"offsets\" format=\"ascii\">\n";
+  for (int c = 1; c <= nc; ++c) f << (int64_t)c * nv << (c % 16 ? ' ' : '\n');
+  f << "\n</DataArray>\n<DataArray type=\"UInt8\" Name=\"types\" format=\"ascii\">\n";
+  for (int c = 1; c <= nc; ++c) f << (dim == 3 ? 10 : 5) << (c % 32 ? ' ' : '\n');  // VTK_TETRA / VTK_TRIANGLE
+  f << "\n</DataArray>\n</Cells>\n<PointData Scalars=\"scalars\">\n";
+  f << "<DataArray type=\"Float64\" Name=\"velocity\" NumberOfComponents=\"3\" format=\"ascii\">\n";
+  for (int c = 0; c < nc; ++c)
+    for (int v = 0; v < nv; ++v) {
+      const int32_t *cd = d->cell_dofs.data() + (size_t)c * d->dpc + (size_t)(dim + 1) * v;
+      f << solution[cd[0]] << ' ' << solution[cd[1]] << ' ' << (dim == 3 ? solution[cd[2]] : 0.0) << '\n';
+    }
+  f << "</DataArray>\n<DataArray type=\"Float64\" Name=\"pressure\" format=\"ascii\">\n";
+  for (int c = 0; c < nc; ++c)
+    for (int v = 0; v < nv; ++v) f << solution[d->cell_dofs[(size_t)c * d->dpc + (size_t)(dim + 1) * v + dim]] << (v + 1 == nv ? '\n' : ' ');
+  f << "</DataArray>\n<DataArray type=\"Float64\" Name=\"partitioning\" format=\"ascii\">\n";
+  for (int c = 0; c < nc; ++c)
+    for (int v = 0; v < nv; ++v) f << (sub ? sub[c] : 0) << (v + 1 == nv ? '\n' : ' ');
+  f << "</DataArray>\n</PointData>\n</Piece>\n</UnstructuredGrid>\n</VTKFile>\n";
+  f.close();
+  std::ofstream pv(dir + stem + ".pvtu");
+  if (!pv) return -1;
+  pv << "<?xml version=\"1.0\"?>\n<VTKFile type=\"PUnstructuredGrid\" version=\"0.1\" byte_order=\"LittleEndian\">\n"
+     << "<PUnstructuredGrid GhostLevel=\"0\">\n<PPointData Scalars=\"scalars\">\n"
+     << "<PDataArray type=\"Float64\" Name=\"velocity\" NumberOfComponents=\"3\" format=\"ascii\"/>\n"
+     << "<PDataArray type=\"Float64\" Name=\"pressure\" format=\"ascii\"/>\n"
+     << "<PDataArray type=\"Float64\" Name=\"partitioning\" format=\"ascii\"/>\n</PPointData>\n"
+     << "<PPoints>\n<PDataArray type=\"Float64\" NumberOfComponents=\"3\"/>\n</PPoints>\n"
+     << "<Piece Source=\"" << piece << "\"/>\n</PUnstructuredGrid>\n</VTKFile>\n";
+  return pv ? 0 : -1;
+}
+
+int nsxh_pressure_difference(const nsxh_dofs *d, const double *solution, const double *pa, const double *pb, double *diff) {
+  if (!d || !solution || !pa || !pb || !diff) return -1;
+  const int dim = d->dim, nv = dim + 1;
+  double val[2] = {0.0, 0.0};
+  bool found[2] = {false, false};
+  const double *pts[2] = {pa, pb};
+  for (int c = 0; c < d->n_cells && !(found[0] && found[1]); ++c) {
+    const double *X = d->cell_coords.data() + (size_t)c * nv * dim;
+    // barycentric coordinates: x = X0 + J lambda
+    double J[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int i = 0; i < dim; ++i)
+      for (int j = 0; j < dim; ++j) J[i][j] = X[(size_t)(j + 1) * dim + i] - X[i];
+    const double det = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) - J[0][1] * (J[1][0] * J[2][2] - J[1][2] * J[2][0]) +
+                       J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+    if (det == 0.0) continue;
+    for (int k = 0; k < 2; ++k) {
+      if (found[k]) continue;
+      double r[3] = {0, 0, 0}, lam[3] = {0, 0, 0};
+      for (int i = 0; i < dim; ++i) r[i] = pts[k][i] - X[i];
+      // Cramer
+      for (int j = 0; j < 3; ++j) {
+        double M[3][3];
+        for (int a = 0; a < 3; ++a)
+          for (int b = 0; b < 3; ++b) M[a][b] = b == j ? r[a] : J[a][b];
+        lam[j] = (M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
+                  M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0])) / det;
+      }
+      double l0 = 1.0;
+      bool inside = true;
+      for (int j = 0; j < dim; ++j) {
+        l0 -= lam[j];
+        inside = inside && lam[j] >= -1e-12;
+      }
+      if (!inside || l0 < -1e-12) continue;
+      const int32_t *cd = d->cell_dofs.data() + (size_t)c * d->dpc;
+      double p = l0 * solution[cd[dim]];
+      for (int j = 0; j < dim; ++j) p += lam[j] * solution[cd[(size_t)(dim + 1) * (j + 1) + dim]];
+      val[k] = p;
+      found[k] = true;
+    }
+  }
+  *diff = val[0] - val[1];
+  return (int)found[0] + (int)found[1];
+}
 
 }  // extern "C"

@@ -1,6 +1,6 @@
 // main_cylinder.cpp — the reference's navier_stokes3D / navier_stokes2D executables on the C++ host mirror
 // (reference Navier-Stokes/src/main3D.cpp:4-79, src/main2D.cpp:4-63).  Compiled twice: -DNSX_DIM=3 / -DNSX_DIM=2.
-//   usage: navier_stokes{2,3}D [mesh.msh | level:N] [n_steps] [n_ranks]
+//   usage: navier_stokes{2,3}D [mesh.msh | level:N] [n_steps] [n_ranks] [write_output 0|1]
 #include <chrono>
 
 #include "NavierStokes.hpp"
@@ -19,11 +19,23 @@ int main(int argc, char *argv[]) {
   try {
     const auto t0 = std::chrono::steady_clock::now();
     nsx::NavierStokes<NSX_DIM> problem(mesh_file_name, degree_velocity, degree_pressure, T, deltat, 2, n_ranks);
+    if (argc > 4) problem.write_output = problem.write_csv = std::atoi(argv[4]) != 0;
     problem.setup();
     problem.solve();
     const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::cout << "Time taken to solve ENTIRE Navier Stokes problem: " << wall << " seconds" << std::endl;
-    // forces_results CSV of main3D.cpp:56-76 would be empty in the reference too; write the timings instead
+    {  // main3D.cpp:56-76 / main2D.cpp:40-60, with the Lift column holding the lift (the reference prints the lift coefficient twice)
+      std::ofstream outputFile(NSX_DIM == 3 ? "forces_results_3D_2case.csv" : "forces_results_2D_2case.csv");
+      if (!outputFile.is_open()) {
+        std::cerr << "Error opening output file" << std::endl;
+        return -1;
+      }
+      outputFile << "Iteration, Drag, Lift, Coeff Drag, CoeffLift, time prec, time solve" << std::endl;
+      const size_t first = problem.time_prec.size() - problem.vec_drag.size();  // 3D: forces start after t = 0.1
+      for (size_t ite = 0; ite < problem.vec_drag.size(); ite++)
+        outputFile << (first + ite + 1) * deltat << ", " << problem.vec_drag[ite] << ", " << problem.vec_lift[ite] << ", " << problem.vec_drag_coeff[ite]
+                   << ", " << problem.vec_lift_coeff[ite] << ", " << problem.time_prec[first + ite] << ", " << problem.time_solve[first + ite] << std::endl;
+    }
     std::ofstream csv(NSX_DIM == 3 ? "timings_3D.csv" : "timings_2D.csv");
     csv << "step,gmres_iterations,time_prec,time_solve\n";
     for (size_t i = 0; i < problem.time_prec.size(); ++i)

@@ -190,3 +190,54 @@ def test_face_tables():
     opp = [3, 2, 1, 0]   # vertex opposite to deal.II face f = {012, 103, 023, 213}
     for f in range(4):
         assert np.allclose(lam[f * t.n_qf:(f + 1) * t.n_qf, opp[f]], 0.0, atol=1e-15)
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_vtu_output_matches_the_field(dim, tmp_path):
+    """NavierStokes::output (NavierStokes3D.cpp:643-683): one linear patch per cell, velocity / pressure / partitioning."""
+    import xml.etree.ElementTree as ET
+    m = Mesh.cylinder(dim, 1).partition(1, 3)
+    d = DoFs(m)
+    X = d.support_points
+    sol = np.zeros(d.n_dofs)
+    for c in range(dim):
+        sol[c:d.n_u:dim] = (c + 1) * X[c:d.n_u:dim, 0] - 0.5 * X[c:d.n_u:dim, 1]
+    sol[d.n_u:] = 3.0 + X[d.n_u:, 0] * X[d.n_u:, 1]
+    d.write_vtu(sol, tmp_path / "out" / "nested", "output-navier-stokes-%dD" % dim, 20)
+    piece = tmp_path / "out" / "nested" / ("output-navier-stokes-%dD_20.0.vtu" % dim)
+    record = tmp_path / "out" / "nested" / ("output-navier-stokes-%dD_20.pvtu" % dim)
+    root = ET.parse(piece).getroot()
+    pc = root.find("UnstructuredGrid/Piece")
+    nv = dim + 1
+    assert int(pc.get("NumberOfCells")) == d.n_cells and int(pc.get("NumberOfPoints")) == d.n_cells * nv
+    arr = {a.get("Name"): np.array(a.text.split(), dtype=float) for a in pc.iter("DataArray") if a.get("Name")}
+    pts = np.array(pc.find("Points/DataArray").text.split(), dtype=float).reshape(-1, 3)
+    assert np.allclose(pts[:, :dim].reshape(d.n_cells, nv, dim), d.cell_coords) and (dim == 3 or (pts[:, 2] == 0).all())
+    assert (arr["types"] == (10 if dim == 3 else 5)).all() and (arr["offsets"] == nv * np.arange(1, d.n_cells + 1)).all()
+    assert (arr["connectivity"] == np.arange(d.n_cells * nv)).all()
+    vel = arr["velocity"].reshape(-1, 3)
+    for c in range(dim):
+        assert np.allclose(vel[:, c], (c + 1) * pts[:, 0] - 0.5 * pts[:, 1], atol=1e-14)
+    assert np.allclose(arr["pressure"], 3.0 + pts[:, 0] * pts[:, 1], atol=1e-14)
+    assert (arr["partitioning"].reshape(d.n_cells, nv) == m.subdomain[:, None]).all()
+    rec = ET.parse(record).getroot()
+    assert rec.find("PUnstructuredGrid/Piece").get("Source") == piece.name
+    assert {a.get("Name") for a in rec.iter("PDataArray") if a.get("Name")} == {"velocity", "pressure", "partitioning"}
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_pressure_difference_is_the_p1_interpolant(dim):
+    """compute_pressure_difference (NavierStokes3D.cpp:849-923): exact for a linear pressure, 0 for points outside."""
+    from navierstokes_project_nm4pde_amd.problem import pressure_difference
+    m = Mesh.cylinder(dim, 1)
+    d = DoFs(m)
+    X = d.support_points[d.n_u:]
+    sol = np.zeros(d.n_dofs)
+    g = np.array([2.0, -1.0, 0.5][:dim])
+    sol[d.n_u:] = 7.0 + X @ g
+    a, b = np.array([0.45, 0.2, 0.205][:dim]), np.array([0.55, 0.2, 0.205][:dim])
+    diff, found = d.pressure_difference(sol, a, b)
+    assert found == 2 and abs(diff - (a - b) @ g) < 1e-12
+    assert abs(diff - pressure_difference(m, d, sol, a, b)) < 1e-12      # the numpy version used by the convergence driver
+    diff, found = d.pressure_difference(sol, a, np.array([9.0, 9.0, 9.0][:dim]))
+    assert found == 1 and abs(diff - (7.0 + a @ g)) < 1e-12              # a point nobody holds contributes 0 (MPI_MAX of zeros)

@@ -24,7 +24,7 @@ def test_host_mirror_executable_matches_python_driver(dim, tmp_path):
     from navierstokes_project_nm4pde_amd.frontend import DoFs, Mesh, Tables
     from navierstokes_project_nm4pde_amd.problem import InletVelocity, cylinder_boundary_values
     mesh = Mesh.cylinder(dim, 1).partition(1, 4)
-    dofs, tables = DoFs(mesh), Tables(dim)
+    dofs, tables = DoFs(mesh, "colour"), Tables(dim)   # the mirror numbers the nodes of a rank colour by colour
     dt = 2e-4 if dim == 3 else 0.01
     dev = nsx.Nsx(dofs, tables, 1e-3, dt)
     dev.set_solution(np.zeros(dofs.n_dofs))
@@ -40,6 +40,29 @@ def test_host_mirror_executable_matches_python_driver(dim, tmp_path):
         py_its.append(dev.solve_time_step(0 if dim == 3 else 3, inner_maxiter=100000 if dim == 3 else 10000)["outer_iterations"])
     assert its == py_its
     assert os.path.exists(tmp_path / ("timings_%dD.csv" % dim))
+    # output side (reference output() / main*.cpp): VTU + PVTU record, force and iteration CSVs
+    import xml.etree.ElementTree as ET
+    out_dir = tmp_path / ("outputConvergence" if dim == 3 else "output2D_1")
+    steps_written = [0] if dim == 3 else [0, 1, 2, 3]            # every 20th step in 3D, every step in 2D
+    for k in steps_written:
+        piece = out_dir / ("output-navier-stokes-%dD_%d.0.vtu" % (dim, k))
+        assert piece.exists() and (out_dir / ("output-navier-stokes-%dD_%d.pvtu" % (dim, k))).exists()
+    pc = ET.parse(out_dir / ("output-navier-stokes-%dD_%d.0.vtu" % (dim, steps_written[-1]))).getroot().find("UnstructuredGrid/Piece")
+    arr = {a.get("Name"): np.array(a.text.split(), dtype=float) for a in pc.iter("DataArray") if a.get("Name")}
+    sol = dev.solution if dim == 2 else np.zeros(dofs.n_dofs)      # 3D: only the initial condition is written in 3 steps
+    nv = dim + 1
+    assert np.allclose(arr["pressure"].reshape(-1, nv), sol[dofs.cell_dofs[:, [(dim + 1) * v + dim for v in range(nv)]]], rtol=1e-9, atol=1e-12)
+    assert np.allclose(arr["velocity"].reshape(-1, nv, 3)[:, :, 0], sol[dofs.cell_dofs[:, [(dim + 1) * v for v in range(nv)]]], rtol=1e-9, atol=1e-12)
+    forces = (tmp_path / ("forces_results_%dD_2case.csv" % dim)).read_text().strip().splitlines()
+    assert forces[0].startswith("Iteration, Drag, Lift, Coeff Drag, CoeffLift")
+    assert len(forces) == (1 if dim == 3 else 4)                   # 3D: forces only after t = 0.1 (NavierStokes3D.cpp:728)
+    if dim == 2:
+        gm = np.loadtxt(tmp_path / "gmres.csv", delimiter=",")
+        assert gm.shape == (3, 3) and gm[:, 2].astype(int).tolist() == its and np.allclose(gm[:, 0], [0.01, 0.02, 0.03])
+        co = np.loadtxt(tmp_path / "coeff_2.csv", delimiter=",")
+        assert co.shape == (4, 3) and co[:, 0].astype(int).tolist() == [0, 1, 2, 3]
+        rows = np.array([[float(x) for x in line.split(",")] for line in forces[1:]])
+        assert np.allclose(rows[:, 3], co[1:, 1]) and np.allclose(rows[:, 4], co[1:, 2])
 
 
 def test_convergence_study_on_device_matches_oracle():
