@@ -107,17 +107,17 @@ def cylinder_boundary_values(dofs, inlet, time):
     call overwriting shared dofs exactly as std::map assignment does (NavierStokes3D.cpp:331-351, 519-539)."""
     inlet.set_time(time)
     dim = dofs.dim
-    bv = {}
-    d0 = dofs.boundary_dofs(0)
-    vals = np.zeros(len(d0))
-    xcomp = (d0 % dim) == 0
-    vals[xcomp] = inlet.value(dofs.support_points[d0[xcomp]])
-    bv.update(zip(d0.tolist(), vals.tolist()))
-    for bid in (2, 3):
-        for d in dofs.boundary_dofs(bid).tolist():
-            bv[d] = 0.0
-    keys = np.array(sorted(bv), dtype=np.int32)
-    return keys, np.array([bv[k] for k in keys.tolist()], dtype=np.float64)
+    cache = getattr(dofs, "_cylinder_bc", None)
+    if cache is None:  # the dof set and who wins on shared dofs do not change with time: only the inlet values do
+        d0 = dofs.boundary_dofs(0)
+        zero = np.unique(np.concatenate([dofs.boundary_dofs(2), dofs.boundary_dofs(3)]))
+        keys = np.union1d(d0, zero).astype(np.int32)
+        inlet_x = np.isin(keys, d0) & ~np.isin(keys, zero) & (keys % dim == 0)
+        cache = dofs._cylinder_bc = (keys, inlet_x, np.ascontiguousarray(dofs.support_points[keys[inlet_x]]))
+    keys, inlet_x, pts = cache
+    vals = np.zeros(len(keys))
+    vals[inlet_x] = inlet.value(pts)
+    return keys, vals
 
 
 def ethier_boundary_values(dofs, exact, time):
