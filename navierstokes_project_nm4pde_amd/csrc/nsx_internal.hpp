@@ -113,6 +113,12 @@ struct IluSchedule {
   DevBuf<int32_t> pk_slot_of;   // [nnz]: slot of every in-block off-diagonal CSR entry, -1 otherwise
   DevBuf<double> pk_val;        // [n_slabs*64] factor values in stream order (padding slots stay 0)
   DevBuf<double> pk_dinv;       // [n_rows] inverse pivots
+  // explicit inverses (k_ilu_invert / k_ilu_apply_dense): P_b = (L D U)^-1 of every block as a dense row-major n_b x n_b
+  // matrix; the triangular solves become one dependency-free dense product per block
+  bool dense = false;
+  DevBuf<int64_t> dn_off;       // [n_blocks+1] offsets of the blocks' matrices in dn_P
+  DevBuf<double> dn_P;
+  int64_t dn_entries = 0;
 };
 
 // Ghost exchange plan of one scalar space (the Epetra_Import of every vmult): neighbours in ascending rank order,
@@ -243,7 +249,8 @@ struct LaunchScope {
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // ---- kernels / steps implemented across the .hip files
-void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> &block_ptr, IluSchedule &s, int lanes_per_row, int blocks_per_wave);
+void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> &block_ptr, IluSchedule &s, int lanes_per_row, int blocks_per_wave,
+                        bool allow_dense = false);
 void build_schur_graph(nsx_handle *h);
 
 // assembly (nsx_assemble.hip)

@@ -65,7 +65,8 @@ static void build_gather(nsx_handle *h, const Csr &g, int n_cells, int per_r, co
   gm.src.upload(src, h->stream);
 }
 
-void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> &bptr, IluSchedule &s, int lanes_per_row, int blocks_per_wave) {
+void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> &bptr, IluSchedule &s, int lanes_per_row, int blocks_per_wave,
+                        bool allow_dense) {
   const int nb = (int)bptr.size() - 1;
   s.n_blocks = nb;
   s.block_ptr_h = bptr;
@@ -272,6 +273,26 @@ void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> 
   s.pk_val.alloc(meta.size());
   s.pk_val.zero(h->stream);
   s.pk_dinv.alloc(g.n_rows);
+
+  // ---- explicit block inverses.  Worth it when the blocks are few, small and deep: the dense matrices of all blocks
+  // together (sum n_b^2) must not cost more traffic than the chain of the sparse sweep costs time.  Used for the Schur
+  // matrix (one component, ~100-row blocks with ~95 dependency levels); the velocity blocks stay sparse.
+  s.dense = false;
+  if (allow_dense) {
+    std::vector<int64_t> off(nb + 1, 0);
+    for (int b = 0; b < nb; ++b) {
+      const int64_t n = bptr[b + 1] - bptr[b];
+      off[b + 1] = off[b] + n * n;
+    }
+    const int64_t limit = getenv("NSX_DENSE_MAX") ? atoll(getenv("NSX_DENSE_MAX")) : ((int64_t)32 << 20);  // entries (256 MB)
+    if (off[nb] > 0 && off[nb] <= limit && s.max_rows <= 4096) {
+      s.dense = true;
+      s.dn_entries = off[nb];
+      s.dn_off.upload(off, h->stream);
+      s.dn_P.alloc((size_t)off[nb]);
+      if (getenv("NSX_DEBUG")) fprintf(stderr, "[nsx] ilu schedule: explicit block inverses, %lld entries (%.1f MB)\n", (long long)off[nb], 8e-6 * off[nb]);
+    }
+  }
 }
 
 void build_blocked(nsx_handle *h, const Csr &g, int R, SpmvBlocked &b) {
@@ -352,7 +373,8 @@ static void refresh_rank_products(nsx_handle *h) {
   const int lwF = getenv("NSX_LW_F") ? atoi(getenv("NSX_LW_F")) : 8, lwS = getenv("NSX_LW_S") ? atoi(getenv("NSX_LW_S")) : 32;
   const int bpwF = getenv("NSX_BPW_F") ? atoi(getenv("NSX_BPW_F")) : 1, bpwS = getenv("NSX_BPW_S") ? atoi(getenv("NSX_BPW_S")) : 1;
   setup_ilu_schedule(h, h->gA.host, h->rank_u_h, h->schedF, lwF, bpwF);
-  setup_ilu_schedule(h, h->gS.host, h->sblk_h.empty() ? h->rank_p_h : h->sblk_h, h->schedS, lwS, bpwS);
+  const bool denseS = !(getenv("NSX_DENSE_S") && atoi(getenv("NSX_DENSE_S")) == 0);
+  setup_ilu_schedule(h, h->gS.host, h->sblk_h.empty() ? h->rank_p_h : h->sblk_h, h->schedS, lwS, bpwS, denseS);
   h->prec_ready = false;
 }
 

@@ -443,6 +443,80 @@ __global__ __launch_bounds__(ILU_WAVES * 64) void k_ilu_factor(const int32_t *__
   }
 }
 
+// ---- explicit block inverses -----------------------------------------------------------------------------------------
+// P_b = U^-1 D^-1 L^-1 of one block (Ifpack storage: strict lower = L, diagonal = 1/d, strict upper = U/d), dense row-major.
+// Thread j owns column j: forward sweep Y e_j = L^-1 e_j row by row, then the backward sweep in place.  Columns are
+// independent, so there is no synchronisation; for a fixed row all threads read the same factor entries (broadcast)
+// and consecutive entries of a row of P (coalesced).
+__global__ __launch_bounds__(256) void k_ilu_invert(const int32_t *__restrict__ bptr, const int64_t *__restrict__ off,
+                                                    const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                    const int32_t *__restrict__ diag, const double *__restrict__ lu, double *P) {
+  const int blk = blockIdx.x, r0 = bptr[blk], n = bptr[blk + 1] - r0;
+  double *Pb = P + off[blk];
+  for (int j = threadIdx.x; j < n; j += 256) {
+    for (int i = 0; i < n; ++i) {  // Y = L^-1 (unit lower)
+      const int row = r0 + i, pe = diag[row];
+      double acc = i == j ? 1.0 : 0.0;
+      for (int p = rp[row]; p < pe; ++p) {
+        const int k = ci[p] - r0;
+        if (k >= 0) acc -= lu[p] * Pb[(size_t)k * n + j];
+      }
+      Pb[(size_t)i * n + j] = acc;
+    }
+    for (int i = n - 1; i >= 0; --i) {  // P = U^-1 (D^-1 Y), in place from the last row up
+      const int row = r0 + i, pd = diag[row], pe = rp[row + 1];
+      double acc = lu[pd] * Pb[(size_t)i * n + j];
+      for (int p = pd + 1; p < pe; ++p) {
+        const int k = ci[p] - r0;
+        if (k < n) acc -= lu[p] * Pb[(size_t)k * n + j];
+      }
+      Pb[(size_t)i * n + j] = acc;
+    }
+  }
+}
+
+// x_b = P_b b_b: 16 lanes per row, 64 row groups per workgroup (a ~100-row block is done in two rounds: the kernel is
+// bound by load latency, not bytes, so the block gets as many loads in flight as the CU allows); optional b . x partial
+constexpr int DENSE_THREADS = 1024;
+__global__ __launch_bounds__(DENSE_THREADS) void k_ilu_apply_dense(const int32_t *__restrict__ bptr, const int64_t *__restrict__ off,
+                                                                   const double *__restrict__ P, const double *b, double *x,
+                                                                   double *__restrict__ dot_partial) {
+  extern __shared__ double bs[];
+  __shared__ double sh[DENSE_THREADS / 64];
+  const int blk = blockIdx.x, r0 = bptr[blk], n = bptr[blk + 1] - r0;
+  const double *Pb = P + off[blk];
+  for (int t = threadIdx.x; t < n; t += DENSE_THREADS) bs[t] = b[r0 + t];
+  __syncthreads();
+  const int grp = threadIdx.x >> 4, lane = threadIdx.x & 15;
+  double dot = 0.0;
+  for (int i = grp; i < n; i += DENSE_THREADS / 16) {
+    const double *row = Pb + (size_t)i * n;
+    double a0 = 0.0, a1 = 0.0;
+    int j = lane;
+    for (; j + 16 < n; j += 32) {  // two independent chains, loads issued back to back
+      a0 += row[j] * bs[j];
+      a1 += row[j + 16] * bs[j + 16];
+    }
+    if (j < n) a0 += row[j] * bs[j];
+    const double acc = lane_group_sum<16>(a0 + a1);
+    if (lane == 0) {
+      x[r0 + i] = acc;
+      dot += bs[i] * acc;
+    }
+  }
+  if (dot_partial) {
+    dot = lane_group_sum<64>(dot);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < DENSE_THREADS / 64; ++k) t += sh[k];
+      dot_partial[blk] = t;
+    }
+  }
+}
+
 void ilu_factor(nsx_handle *h, const DevCsr &g, IluSchedule &s, const double *vals, double *lu, const char *name) {
   int *err = (int *)(h->scal.p + (N_SLOTS - 1));
   HIP_CHECK(hipMemsetAsync(err, 0, sizeof(double), h->stream));
@@ -457,6 +531,11 @@ void ilu_factor(nsx_handle *h, const DevCsr &g, IluSchedule &s, const double *va
   HIP_CHECK(hipStreamSynchronize(h->stream));
   if (herr == 1) NSX_THROW(NSX_ERR_UNSUPPORTED, "ILU: a row has more than %d entries", ILU_MAXROW);
   if (herr == 2) NSX_THROW(NSX_ERR_NUMERIC, "ILU: zero pivot");
+  if (s.dense) {
+    LaunchScope ls(h, "ilu_invert", 8.0 * (double)s.dn_entries + 12.0 * g.nnz());
+    hipLaunchKernelGGL(k_ilu_invert, dim3(s.n_blocks), dim3(256), 0, h->stream, s.block_ptr.p, s.dn_off.p, g.rowptr.p, g.colind.p, g.diag.p, lu,
+                       s.dn_P.p);
+  }
 }
 
 // x = U^{-1} D^{-1} L^{-1} b per block (Ifpack_ILU::ApplyInverse), NCOMP right-hand sides interleaved.
@@ -714,6 +793,14 @@ static void launch_ilu_solve(nsx_handle *h, const DevCsr &g, const IluSchedule &
 bool ilu_solve(nsx_handle *h, const DevCsr &g, const IluSchedule &s, const double *lu, const double *b, double *x, int ncomp,
                const char *name, int dot_slot) {
   const bool packed = s.packed_ok && (size_t)s.max_wave_rows * ncomp * sizeof(double) <= 64 * 1024;
+  if (s.dense && ncomp == 1 && (size_t)s.max_rows * sizeof(double) <= 48 * 1024) {
+    LaunchScope ls(h, name, 8.0 * (double)s.dn_entries + 16.0 * g.n_rows());
+    const bool with_dot = dot_slot >= 0 && s.n_blocks >= 2 && s.n_blocks <= 512;
+    hipLaunchKernelGGL(k_ilu_apply_dense, dim3(s.n_blocks), dim3(DENSE_THREADS), (size_t)s.max_rows * sizeof(double), h->stream, s.block_ptr.p, s.dn_off.p,
+                       s.dn_P.p, b, x, with_dot ? red_out(h, dot_slot, s.n_blocks) : nullptr);
+    if (with_dot) after_reduction(h, dot_slot, s.n_blocks);
+    return with_dot;
+  }
   // algorithmic bytes: the CSR factor once (12 B/entry) + rhs/solution vectors; the packed stream moves 768 B per slab
   LaunchScope ls(h, name, 12.0 * g.nnz() + (double)g.n_rows() * (4 + 16.0 * ncomp));
   if (packed) {
