@@ -102,7 +102,7 @@ struct IluSchedule {
   DevBuf<int32_t> blk_lvl_off;           // [n_blocks+1] offsets into fwd_lvl_ptr (levels per block), same for bwd
   DevBuf<int32_t> blk_lvl_off_b;
   int max_levels = 0;
-  // packed solve stream (one wave per group of blocks): slabs of 64 slots {value, meta}; meta = col | last_of_step<<15 | (dst_row+1)<<16
+  // packed solve stream (one wave per group of blocks): slabs of 64 slots {value, meta}; meta = col | last_of_step<<15 | (dst_row+1)<<16 | row_uses_a_pair_of_groups<<31
   int lanes_per_row = 8;
   int64_t n_slabs = 0;
   int blocks_per_wave = 1, n_waves = 0, max_wave_rows = 0;
@@ -250,7 +250,7 @@ inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // ---- kernels / steps implemented across the .hip files
 void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> &block_ptr, IluSchedule &s, int lanes_per_row, int blocks_per_wave,
-                        bool allow_dense = false);
+                        bool allow_dense = false, bool allow_wide_rows = false);
 void build_schur_graph(nsx_handle *h);
 
 // assembly (nsx_assemble.hip)

@@ -66,7 +66,7 @@ static void build_gather(nsx_handle *h, const Csr &g, int n_cells, int per_r, co
 }
 
 void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> &bptr, IluSchedule &s, int lanes_per_row, int blocks_per_wave,
-                        bool allow_dense) {
+                        bool allow_dense, bool allow_wide_rows) {
   const int nb = (int)bptr.size() - 1;
   s.n_blocks = nb;
   s.block_ptr_h = bptr;
@@ -133,6 +133,7 @@ void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> 
   // A step occupies K slabs of 64 slots, slot (k, lane) = entry lane%LW + k*LW of row-group lane/LW.  Columns and
   // destinations are row indices into the wave's LDS copy of x (its blocks back to back).
   const int LW = lanes_per_row, G = 64 / LW, BPW = std::max(1, blocks_per_wave);
+  const bool allow_wide = allow_wide_rows && LW == 8;  // the pair sum is implemented for 8-lane groups (one 16-lane DPP row)
   s.lanes_per_row = LW;
   s.blocks_per_wave = BPW;
   const int nw = (nb + BPW - 1) / BPW;
@@ -199,38 +200,69 @@ void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> 
       std::vector<int32_t> step_rows;
       while (done < work.size()) {
         if (ready.empty()) NSX_THROW(NSX_ERR_ARG, "internal: ILU schedule has a dependency cycle");
-        // pick the G rows with the longest remaining chains (ties: lowest row index, deterministic)
-        const size_t take = std::min<size_t>(G, ready.size());
-        std::partial_sort(ready.begin(), ready.begin() + take, ready.end(), [](const std::pair<int32_t, int32_t> &x, const std::pair<int32_t, int32_t> &y) {
+        // pick rows with the longest remaining chains first (ties: lowest row index, deterministic) until the G lane groups
+        // of the step are taken.  A row with more than LW entries may take an aligned PAIR of groups (allow_wide: the
+        // kernel adds the two group sums with one more DPP stage), so that it does not force a second slab on everybody.
+        std::sort(ready.begin(), ready.end(), [](const std::pair<int32_t, int32_t> &x, const std::pair<int32_t, int32_t> &y) {
           return x.first != y.first ? x.first > y.first : x.second < y.second;
         });
+        std::vector<int32_t> wide_rows, narrow_rows;
+        std::vector<char> taken(ready.size(), 0);
+        int used = 0;
+        for (size_t k = 0; k < ready.size() && used < G; ++k) {
+          const int i = ready[k].second;
+          const bool wide = allow_wide && G >= 2 && indeg[i] > LW;
+          const int need = wide ? 2 : 1;
+          if (used + need > G) continue;
+          (wide ? wide_rows : narrow_rows).push_back(i);
+          used += need;
+          taken[k] = 1;
+        }
+        {
+          size_t o = 0;
+          for (size_t k = 0; k < ready.size(); ++k)
+            if (!taken[k]) ready[o++] = ready[k];
+          ready.resize(o);
+        }
         step_rows.clear();
-        for (size_t k = 0; k < take; ++k) step_rows.push_back(ready[k].second);
-        ready.erase(ready.begin(), ready.begin() + take);
-        const int ng = (int)step_rows.size();
+        int row_of_group[64], sub_of_group[64];  // G <= 64
+        for (int gi = 0; gi < G; ++gi) row_of_group[gi] = -1, sub_of_group[gi] = 0;
+        for (size_t k = 0; k < wide_rows.size(); ++k) {
+          row_of_group[2 * k] = row_of_group[2 * k + 1] = (int)step_rows.size();
+          sub_of_group[2 * k + 1] = 1;
+          step_rows.push_back(wide_rows[k]);
+        }
+        for (size_t k = 0; k < narrow_rows.size(); ++k) {
+          row_of_group[2 * wide_rows.size() + k] = (int)step_rows.size();
+          step_rows.push_back(narrow_rows[k]);
+        }
+        const int ng = (int)step_rows.size(), n_wide = (int)wide_rows.size();
         std::vector<std::vector<int32_t>> ent(ng);
         int K = 1;
-        for (int gi = 0; gi < ng; ++gi) {
-          const int i = step_rows[gi];
+        for (int r = 0; r < ng; ++r) {
+          const int i = step_rows[r];
           const int b = (int)(std::upper_bound(bptr.begin(), bptr.end(), i) - bptr.begin()) - 1;
           for (int q = g.rowptr[i]; q < g.rowptr[i + 1]; ++q)
-            if (in_part(i, g.colind[q], bptr[b], bptr[b + 1])) ent[gi].push_back(q);
-          K = std::max(K, ((int)ent[gi].size() + LW - 1) / LW);
+            if (in_part(i, g.colind[q], bptr[b], bptr[b + 1])) ent[r].push_back(q);
+          const int lanes = r < n_wide ? 2 * LW : LW;
+          K = std::max(K, ((int)ent[r].size() + lanes - 1) / lanes);
         }
         for (int k = 0; k < K; ++k) {
           const size_t base = meta.size();
           meta.resize(base + 64, 0);
           for (int lane = 0; lane < 64; ++lane) {
-            const int gi = lane / LW, l = lane % LW;
+            const int gi = lane / LW, l = lane % LW, r = row_of_group[gi];
             int32_t m = (k == K - 1) ? 0x8000 : 0;
-            if (gi < ng) {
-              const size_t e = (size_t)l + (size_t)k * LW;
-              if (e < ent[gi].size()) {
-                const int q = ent[gi][e];
+            if (r >= 0) {
+              const bool wide = r < n_wide;
+              const size_t e = wide ? (size_t)sub_of_group[gi] * LW + l + (size_t)k * 2 * LW : (size_t)l + (size_t)k * LW;
+              if (e < ent[r].size()) {
+                const int q = ent[r][e];
                 m |= xoff[g.colind[q]];
                 slot_of[q] = (int32_t)(base + lane);
               }
-              if (k == K - 1) m |= (xoff[step_rows[gi]] + 1) << 16;  // destination row, known to every lane of the group
+              // destination row (and the pair flag) in every lane of the row's FIRST group
+              if (k == K - 1 && sub_of_group[gi] == 0) m |= ((xoff[step_rows[r]] + 1) << 16) | (wide ? (int32_t)0x80000000 : 0);
             }
             meta[base + lane] = m;
           }
@@ -257,7 +289,7 @@ void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> 
     max_steps = std::max(max_steps, wave_steps);
   }
   s.n_slabs = (int64_t)meta.size() / 64;
-  s.packed_ok = s.max_wave_rows <= 32766;
+  s.packed_ok = s.max_wave_rows <= 32766;  // 15-bit column and destination fields
   if (getenv("NSX_DEBUG")) {
     int64_t max_slabs = 0, used = 0;
     for (int w = 0; w < nw; ++w) max_slabs = std::max<int64_t>(max_slabs, slab_ptr[2 * w + 2] - slab_ptr[2 * w]);
@@ -372,7 +404,8 @@ static void refresh_rank_products(nsx_handle *h) {
   h->dbar.alloc(h->rank_u_h.size() - 1);
   const int lwF = getenv("NSX_LW_F") ? atoi(getenv("NSX_LW_F")) : 8, lwS = getenv("NSX_LW_S") ? atoi(getenv("NSX_LW_S")) : 32;
   const int bpwF = getenv("NSX_BPW_F") ? atoi(getenv("NSX_BPW_F")) : 1, bpwS = getenv("NSX_BPW_S") ? atoi(getenv("NSX_BPW_S")) : 1;
-  setup_ilu_schedule(h, h->gA.host, h->rank_u_h, h->schedF, lwF, bpwF);
+  const bool wideF = !(getenv("NSX_WIDE") && atoi(getenv("NSX_WIDE")) == 0);
+  setup_ilu_schedule(h, h->gA.host, h->rank_u_h, h->schedF, lwF, bpwF, false, wideF && h->dim > 1);
   const bool denseS = !(getenv("NSX_DENSE_S") && atoi(getenv("NSX_DENSE_S")) == 0);
   setup_ilu_schedule(h, h->gS.host, h->sblk_h.empty() ? h->rank_p_h : h->sblk_h, h->schedS, lwS, bpwS, denseS);
   h->prec_ready = false;

@@ -626,8 +626,10 @@ __global__ __launch_bounds__(256) void k_ilu_solve(const int32_t *__restrict__ b
 // own entry of x (the stream stores the destination row in lanes 0..3 of a group).
 template <int NCOMP, int LW>
 __device__ __forceinline__ void packed_slab(double v, int mk, double (&acc)[NCOMP], double *xs, int lane) {
-  const bool last = (mk & 0x8000) != 0;  // last slab of the step (wave-uniform)
-  const int dst = (mk >> 16) & 0xffff, l = lane % LW;
+  // last slab of the step: the flag is set in every lane; reading it from lane 0 makes the branch a scalar one (no
+  // exec-mask bookkeeping around the reduction)
+  const bool last = (__builtin_amdgcn_readfirstlane(mk) & 0x8000) != 0;
+  const int dst = (mk >> 16) & 0x7fff, l = lane % LW;  // bit 31: the row occupies this group AND the next one (LW == 8)
   constexpr bool MERGED = NCOMP > 1 && NCOMP <= 4 && LW >= 8;
   constexpr bool SCALAR = NCOMP == 1 && LW >= 4;
   // lane of the group that ends up with the sum in the one-component path: lane 0 up to 16 lanes per row (all lanes of
@@ -657,10 +659,22 @@ __device__ __forceinline__ void packed_slab(double v, int mk, double (&acc)[NCOM
         t += dpp_f64<0x4E>(t);  // quad_perm [2,3,0,1]
         r[c] = t;
       }
+      // lane q of a quad keeps component q: selected half by half with integer conditional moves (written as a ?: on the
+      // doubles, hipcc turns the selection into nested divergent branches)
       const int q = lane & 3;
-      double w = q == 0 ? r[0] : (q == 1 ? r[1] : (q == 2 ? r[2] : r[3]));
+      int wlo = __double2loint(r[0]), whi = __double2hiint(r[0]);
+#pragma unroll
+      for (int c = 1; c < NCOMP; ++c) {
+        wlo = q == c ? __double2loint(r[c]) : wlo;
+        whi = q == c ? __double2hiint(r[c]) : whi;
+      }
+      double w = __hiloint2double(whi, wlo);
       // row_ror:n hands lane i the value of lane (i - n) mod 16 of its 16-lane row
-      if (LW == 8) w += dpp_f64<0x12C>(w);   // row_ror:12: lane i += lane i+4 (the second quad of the 8-lane group)
+      if (LW == 8) {
+        w += dpp_f64<0x12C>(w);                      // row_ror:12: lane i += lane i+4 (the second quad of the 8-lane group)
+        const double pair = w + dpp_f64<0x128>(w);   // row_ror:8: + the sum of the neighbouring group (lanes i+8)
+        w = mk < 0 ? pair : w;
+      }
       if (LW >= 16) w += dpp_f64<0x124>(w);  // row_ror:4 then row_ror:8: every lane ends with the sum of its residue class mod 4
       if (LW >= 16) w += dpp_f64<0x128>(w);
       if (LW >= 32) w += __shfl_xor(w, 16, 64);
