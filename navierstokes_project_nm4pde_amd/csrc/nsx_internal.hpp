@@ -144,7 +144,7 @@ struct SpmvBlocked {
 
 struct ProfEntry {
   int64_t launches = 0;
-  double bytes = 0;  // algorithmic bytes of one launch (last seen)
+  double bytes = 0;  // algorithmic bytes summed over the launches (a scope's size may vary: Gram-Schmidt sweeps)
   double ms = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
 };
@@ -233,7 +233,7 @@ struct LaunchScope {
   LaunchScope(nsx_handle *h_, const char *name, double bytes) : h(h_) {
     if (!h->prof_on) return;
     e = &h->prof[name];
-    e->bytes = bytes;
+    e->bytes += bytes;
     (void)hipEventCreate(&a);
     (void)hipEventCreate(&b);
     (void)hipEventRecord(a, h->stream);

@@ -988,7 +988,7 @@ int nsx_profile_get(nsx_handle *h, int i, const char **name, int64_t *launches, 
   if (name) *name = h->prof_names[i].c_str();
   if (launches) *launches = e.launches;
   if (total_ms) *total_ms = e.ms;
-  if (bytes) *bytes = e.bytes;
+  if (bytes) *bytes = e.launches ? e.bytes / (double)e.launches : 0.0;  // average algorithmic bytes per launch
   return NSX_OK;
 }
 
