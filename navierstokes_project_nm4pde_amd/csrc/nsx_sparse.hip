@@ -517,14 +517,89 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_ilu_apply_dense(const int32_t
   }
 }
 
+// Same factorisation for blocks of at most ILU_DENSE_ROWS rows: every wave keeps its row as a DENSE vector over the block's
+// columns in LDS (pos[c] = entry index of column c in the row, -1 outside the pattern), so an update is one LDS lookup
+// instead of a binary search through global memory.  Same operations on the same entries in the same order.
+constexpr int ILU_DENSE_ROWS = 512;
+__global__ __launch_bounds__(ILU_WAVES * 64) void k_ilu_factor_small(const int32_t *__restrict__ bptr, const int32_t *__restrict__ lvl_off,
+                                                                    const int32_t *__restrict__ lvl_ptr, const int32_t *__restrict__ lvl_rows,
+                                                                    const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                                    const int32_t *__restrict__ diag, const double *__restrict__ a,
+                                                                    double *__restrict__ lu, const int32_t *__restrict__ slot_of,
+                                                                    double *__restrict__ pk_val, double *__restrict__ pk_dinv,
+                                                                    int *__restrict__ err) {
+  __shared__ double wv[ILU_WAVES][ILU_DENSE_ROWS];
+  __shared__ short posv[ILU_WAVES][ILU_DENSE_ROWS];
+  const int blk = blockIdx.x, wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+  const int r0 = bptr[blk], r1 = bptr[blk + 1], nb = r1 - r0;
+  volatile double *w = wv[wave];  // indexed by block-local column
+  volatile short *pos = posv[wave];
+  for (int lv = lvl_off[blk]; lv < lvl_off[blk + 1]; ++lv) {
+    const int l0 = lvl_ptr[lv], cnt = lvl_ptr[lv + 1] - l0;
+    for (int r = wave; r < cnt; r += ILU_WAVES) {
+      const int i = lvl_rows[l0 + r];
+      const int p0 = rp[i], n = rp[i + 1] - p0, dpos = diag[i] - p0;
+      for (int t = lane; t < nb; t += 64) pos[t] = -1;
+      __builtin_amdgcn_wave_barrier();
+      for (int t = lane; t < n; t += 64) {
+        const int c = ci[p0 + t] - r0;
+        if (c >= 0 && c < nb) {
+          pos[c] = (short)t;
+          w[c] = a[p0 + t];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (int t = 0; t < dpos; ++t) {  // L part, ascending columns (wave-uniform loop)
+        const int j = ci[p0 + t];
+        if (j < r0) continue;
+        const int dj = diag[j];
+        const double mult = w[j - r0];
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) w[j - r0] = mult * lu[dj];  // InV[jj] *= DV[j]
+        const int ue = rp[j + 1];
+        for (int q = dj + 1 + lane; q < ue; q += 64) {  // scaled U row of j
+          const int c = ci[q] - r0;
+          if (c >= nb) break;
+          if (pos[c] >= 0) w[c] -= mult * lu[q];
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      const double d = w[i - r0];
+      const double dinv = 1.0 / d;
+      if (lane == 0 && !(fabs(d) > 0.0)) *err = 2;
+      for (int t = lane; t < n; t += 64) {
+        const int j = ci[p0 + t], c = j - r0;
+        const bool in = c >= 0 && c < nb;
+        double v = in ? w[c] : 0.0;
+        if (t == dpos) v = dinv;
+        else if (t > dpos) v = in ? v * dinv : 0.0;
+        lu[p0 + t] = v;
+        if (slot_of) {
+          const int sl = slot_of[p0 + t];
+          if (sl >= 0) pk_val[sl] = v;
+          if (t == dpos) pk_dinv[i] = dinv;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();  // rows of the next level read the U rows written here (same CU: L1 is coherent for the workgroup)
+  }
+}
+
 void ilu_factor(nsx_handle *h, const DevCsr &g, IluSchedule &s, const double *vals, double *lu, const char *name) {
   int *err = (int *)(h->scal.p + (N_SLOTS - 1));
   HIP_CHECK(hipMemsetAsync(err, 0, sizeof(double), h->stream));
   {
     LaunchScope ls(h, name, 20.0 * g.nnz() + 12.0 * g.n_rows());
-    hipLaunchKernelGGL(k_ilu_factor, dim3(s.n_blocks), dim3(ILU_WAVES * 64), 0, h->stream, s.block_ptr.p, s.blk_lvl_off.p, s.fwd_lvl_ptr.p,
-                       s.fwd_rows.p, g.rowptr.p, g.colind.p, g.diag.p, vals, lu, s.packed_ok ? s.pk_slot_of.p : nullptr, s.pk_val.p,
-                       s.pk_dinv.p, err);
+    static const bool small_ok = !(getenv("NSX_ILU_SMALL") && atoi(getenv("NSX_ILU_SMALL")) == 0);
+    if (small_ok && s.max_rows <= ILU_DENSE_ROWS)
+      hipLaunchKernelGGL(k_ilu_factor_small, dim3(s.n_blocks), dim3(ILU_WAVES * 64), 0, h->stream, s.block_ptr.p, s.blk_lvl_off.p,
+                         s.fwd_lvl_ptr.p, s.fwd_rows.p, g.rowptr.p, g.colind.p, g.diag.p, vals, lu, s.packed_ok ? s.pk_slot_of.p : nullptr,
+                         s.pk_val.p, s.pk_dinv.p, err);
+    else
+      hipLaunchKernelGGL(k_ilu_factor, dim3(s.n_blocks), dim3(ILU_WAVES * 64), 0, h->stream, s.block_ptr.p, s.blk_lvl_off.p, s.fwd_lvl_ptr.p,
+                         s.fwd_rows.p, g.rowptr.p, g.colind.p, g.diag.p, vals, lu, s.packed_ok ? s.pk_slot_of.p : nullptr, s.pk_val.p,
+                         s.pk_dinv.p, err);
   }
   int herr = 0;
   HIP_CHECK(hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
