@@ -17,12 +17,16 @@ def main():
     from navierstokes_project_nm4pde_amd.problem import InletVelocity, cylinder_boundary_values
     dim, level, n_sub, prec = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
     out_path = sys.argv[5]
+    ordering = sys.argv[6] if len(sys.argv) > 6 else "first_touch"
+    schur_merge = int(sys.argv[7]) if len(sys.argv) > 7 else 0
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     mesh = Mesh.cylinder(dim, level).partition(world, n_sub)
-    dofs, tables = DoFs(mesh), Tables(dim)
+    dofs, tables = DoFs(mesh, ordering), Tables(dim)
     dt = 2e-4 if dim == 3 else 1e-2
     dev = nsx.Nsx(dofs, tables, 1e-3, dt, device=0, rank=rank, world=world, comm="callbacks")
+    if schur_merge:  # coarser Schur ILU blocks (unions of this rank's consecutive sub-ranks), as bench.py sets them
+        dev.set_schur_blocks(np.ascontiguousarray(dofs.owned_p_ptr[rank * n_sub:(rank + 1) * n_sub + 1][::schur_merge]))
     inlet = InletVelocity(dim, 2 if dim == 3 else 3)
     rng = np.random.default_rng(5)
     u0 = 0.05 * rng.standard_normal(dofs.n_dofs)

@@ -12,12 +12,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("dim,level,world,n_sub,prec", [(3, 1, 2, 3, 0), (2, 2, 3, 2, 3)])
-def test_distributed_solve_equals_single_process(tmp_path, dim, level, world, n_sub, prec):
+@pytest.mark.parametrize("dim,level,world,n_sub,prec,ordering,schur_merge",
+                         [(3, 1, 2, 3, 0, "first_touch", 0), (2, 2, 3, 2, 3, "first_touch", 0),
+                          (3, 1, 2, 4, 0, "colour", 2)])   # the bench's options: colour order, merged Schur blocks (dense inverses + fused dot)
+def test_distributed_solve_equals_single_process(tmp_path, dim, level, world, n_sub, prec, ordering, schur_merge):
     out = tmp_path / "dist.npz"
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", "29577", os.path.join(ROOT, "tests", "dist_worker.py"), str(dim), str(level), str(n_sub), str(prec), str(out)]
+           "--master-port", "29577", os.path.join(ROOT, "tests", "dist_worker.py"), str(dim), str(level), str(n_sub), str(prec), str(out), ordering, str(schur_merge)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     d = np.load(out)
@@ -26,9 +28,11 @@ def test_distributed_solve_equals_single_process(tmp_path, dim, level, world, n_
     from navierstokes_project_nm4pde_amd.frontend import DoFs, Mesh, Tables
     from navierstokes_project_nm4pde_amd.problem import InletVelocity, cylinder_boundary_values
     mesh = Mesh.cylinder(dim, level).partition(world, n_sub)
-    dofs, tables = DoFs(mesh), Tables(dim)
+    dofs, tables = DoFs(mesh, ordering), Tables(dim)
     dt = 2e-4 if dim == 3 else 1e-2
     dev = nsx.Nsx(dofs, tables, 1e-3, dt)
+    if schur_merge:
+        dev.set_schur_blocks(np.ascontiguousarray(dofs.owned_p_ptr[::schur_merge]))
     dev.set_solution(d["u0"])
     inlet = InletVelocity(dim, 2 if dim == 3 else 3)
     t = 0.0
