@@ -6,7 +6,8 @@
 // order while it starts up, so a dot product costs one launch, not two (a separate 1-block finalise kernel measured
 // 4.6 us x 13 000 launches per step, profiles/r01).  Coefficients are SRef = c * value(num) / value(den) evaluated on the
 // device.  Everything is deterministic: fixed grids, fixed-order sums, no atomics.
-// Multi-GPU: a reduction is finalised at once and all-reduced over RCCL (comm_allreduce_scalars), consumers then read scal[].
+// Multi-GPU: every rank leaves the same number of partial sums, they are all-reduced element-wise over RCCL
+// (comm_allreduce_partials) and consumed exactly as on one GPU.
 #include "nsx_internal.hpp"
 
 namespace nsx {
@@ -150,7 +151,10 @@ __global__ __launch_bounds__(256) void k_publish(int slot0, int count, NbArgs nb
   }
 }
 
-static int red_blocks(int n) { return std::max(1, std::min(RED_BLOCKS, cdiv(n, 1024))); }
+// Number of per-block partial sums of a reduction over n entries.  With a communicator every rank must use the SAME count
+// (the partial sums are all-reduced element by element, see after_reduction), whatever its local size: a fixed grid.
+constexpr int DIST_RED_BLOCKS = 256;
+static int red_blocks(nsx_handle *h, int n) { return h->comm ? DIST_RED_BLOCKS : std::max(1, std::min(RED_BLOCKS, cdiv(n, 1024))); }
 
 static SRef sref(nsx_handle *h, double c, int num, int den) {
   return SRef{c, num, den, num >= 0 ? h->slot_nb[num] : 0, den >= 0 ? h->slot_nb[den] : 0};
@@ -170,7 +174,13 @@ void finalize_slots(nsx_handle *h, int slot0, int count) {
 
 void after_reduction(nsx_handle *h, int slot, int nb) {
   h->slot_nb[slot] = nb > 1 ? nb : 0;
-  if (h->comm) {  // global sum needed before anybody consumes the value
+  if (!h->comm) return;
+  // global sum needed before anybody consumes the value
+  if (nb == DIST_RED_BLOCKS) {
+    // all-reduce the partial sums themselves (2 KB instead of 8 B costs the same latency) and let the consumer add
+    // them up as on one GPU: no finalising launch in front of the collective
+    comm_allreduce_partials(h, h->red_partial.p + (size_t)slot * RED_STRIDE, nb);
+  } else {
     finalize_slots(h, slot, 1);
     comm_allreduce_scalars(h, slot, 1);
   }
@@ -182,7 +192,7 @@ double *red_out(nsx_handle *h, int slot, int nb) {
 void v_dot(nsx_handle *h, Span sp, const double *a, const double *b, int slot) {
   const int n = sp.n;
   LaunchScope ls(h, "dot", (a == b ? 8.0 : 16.0) * n);
-  const int nb = red_blocks(n);
+  const int nb = red_blocks(h, n);
   hipLaunchKernelGGL((k_reduce<OP_DOT>), dim3(nb), dim3(256), 0, h->stream, n, sp.split, sp.gap, const_cast<double *>(a), SRef{0, -1, -1, 0, 0}, nullptr, b,
                      h->scal.p, h->red_partial.p, red_out(h, slot, nb));
   after_reduction(h, slot, nb);
@@ -191,7 +201,7 @@ void v_dot(nsx_handle *h, Span sp, const double *a, const double *b, int slot) {
 void v_add_and_dot(nsx_handle *h, Span sp, double *d, double a, int aslot, const double *v, const double *w, int slot) {
   const int n = sp.n;
   LaunchScope ls(h, "add_and_dot", (w == d ? 24.0 : 32.0) * n);
-  const int nb = red_blocks(n);
+  const int nb = red_blocks(h, n);
   hipLaunchKernelGGL((k_reduce<OP_ADD_AND_DOT>), dim3(nb), dim3(256), 0, h->stream, n, sp.split, sp.gap, d, sref(h, a, aslot, -1), v, w, h->scal.p,
                      h->red_partial.p, red_out(h, slot, nb));
   after_reduction(h, slot, nb);
@@ -502,7 +512,7 @@ void v_axpy_multi(nsx_handle *h, Span sp, double *x, int k, double *const *vs, c
 // SolverCG helpers
 void cg_update(nsx_handle *h, int n, double *x, const double *d, double *g, const double *hv, int gh_slot, int dh_slot, int res_slot) {
   LaunchScope ls(h, "cg_update", 48.0 * n);
-  const int nb = red_blocks(n);
+  const int nb = red_blocks(h, n);
   hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(256), 0, h->stream, n, x, d, g, hv, sref(h, 1, gh_slot, dh_slot), h->scal.p,
                      h->red_partial.p, red_out(h, res_slot, nb));
   after_reduction(h, res_slot, nb);

@@ -21,6 +21,7 @@ struct Comm {
   nsx_allreduce_fn allreduce = nullptr;
   nsx_exchange_fn exchange = nullptr;
   void *ctx = nullptr;
+  std::vector<double> stage;  // host staging of the callback backend
 };
 
 #define NCCL_CHECK(expr)                                                                              \
@@ -39,6 +40,21 @@ void comm_allreduce_scalars(nsx_handle *h, int slot0, int count) {
     HIP_CHECK(hipStreamSynchronize(h->stream));
     if (c->allreduce(c->ctx, h->scal_host + slot0, count)) NSX_THROW(NSX_ERR_COMM, "allreduce callback failed");
     HIP_CHECK(hipMemcpyAsync(h->scal.p + slot0, h->scal_host + slot0, (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+  }
+}
+
+void comm_allreduce_partials(nsx_handle *h, double *partials, int count) {
+  Comm *c = h->comm;
+  if (!c || (c->world == 1 && !c->comm)) return;
+  if (c->comm) {
+    NCCL_CHECK(ncclAllReduce(partials, partials, count, ncclDouble, ncclSum, c->comm, h->stream));
+  } else {
+    c->stage.resize((size_t)count);
+    HIP_CHECK(hipMemcpyAsync(c->stage.data(), partials, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (c->allreduce(c->ctx, c->stage.data(), count)) NSX_THROW(NSX_ERR_COMM, "allreduce callback failed");
+    HIP_CHECK(hipMemcpyAsync(partials, c->stage.data(), (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_CHECK(hipStreamSynchronize(h->stream));
   }
 }

@@ -333,6 +333,7 @@ void solve_time_step(nsx_handle *h, int type, double tol, double inner_rtol, int
 
 // comm (nsx_comm.hip)
 void comm_allreduce_scalars(nsx_handle *h, int slot0, int count);
+void comm_allreduce_partials(nsx_handle *h, double *partials, int count);  // in place, same count on every rank
 void comm_halo(nsx_handle *h, HaloPlan &plan, double *x, int ncomp);
 inline void comm_halo_u(nsx_handle *h, const double *x) { if (h->dist) comm_halo(h, h->haloU, const_cast<double *>(x), h->dim); }
 inline void comm_halo_p(nsx_handle *h, const double *x) { if (h->dist) comm_halo(h, h->haloP, const_cast<double *>(x), 1); }

@@ -884,7 +884,7 @@ bool ilu_solve(nsx_handle *h, const DevCsr &g, const IluSchedule &s, const doubl
   const bool packed = s.packed_ok && (size_t)s.max_wave_rows * ncomp * sizeof(double) <= 64 * 1024;
   if (s.dense && ncomp == 1 && (size_t)s.max_rows * sizeof(double) <= 48 * 1024) {
     LaunchScope ls(h, name, 8.0 * (double)s.dn_entries + 16.0 * g.n_rows());
-    const bool with_dot = dot_slot >= 0 && s.n_blocks >= 2 && s.n_blocks <= 512;
+    const bool with_dot = dot_slot >= 0 && !h->comm && s.n_blocks >= 2 && s.n_blocks <= 512;  // a communicator needs equal counts on all ranks
     hipLaunchKernelGGL(k_ilu_apply_dense, dim3(s.n_blocks), dim3(DENSE_THREADS), (size_t)s.max_rows * sizeof(double), h->stream, s.block_ptr.p, s.dn_off.p,
                        s.dn_P.p, b, x, with_dot ? red_out(h, dot_slot, s.n_blocks) : nullptr);
     if (with_dot) after_reduction(h, dot_slot, s.n_blocks);
@@ -894,7 +894,7 @@ bool ilu_solve(nsx_handle *h, const DevCsr &g, const IluSchedule &s, const doubl
   LaunchScope ls(h, name, 12.0 * g.nnz() + (double)g.n_rows() * (4 + 16.0 * ncomp));
   if (packed) {
     const int lw = s.lanes_per_row;
-    const bool with_dot = dot_slot >= 0 && s.n_waves >= 2 && s.n_waves <= 512;  // one partial sum per wave
+    const bool with_dot = dot_slot >= 0 && !h->comm && s.n_waves >= 2 && s.n_waves <= 512;  // one partial sum per wave
     double *dp = with_dot ? red_out(h, dot_slot, s.n_waves) : nullptr;
 #define NSX_PK(NC)                                                    \
     if (lw == 8) launch_packed<NC, 8>(h, s, b, x, dp);                \
