@@ -28,12 +28,14 @@ $(DEV_SO): $(DEV_SRC) $(DEV_HDR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(DEV_SRC) -L/opt/rocm/lib -lrccl
 
 # C++ host mirror of the reference executables (link against the in-tree libraries)
-MIRROR_BIN := $(PKG)/host/navier_stokes3D $(PKG)/host/navier_stokes2D
+MIRROR_BIN := $(PKG)/host/navier_stokes3D $(PKG)/host/navier_stokes2D $(PKG)/host/convergence
 mirror: $(MIRROR_BIN)
 $(PKG)/host/navier_stokes3D: $(PKG)/host/main_cylinder.cpp $(PKG)/host/NavierStokes.hpp $(HOST_SO) $(DEV_SO)
 	$(CXX) $(CXXFLAGS) -DNSX_DIM=3 -o $@ $< -L$(PKG)/host -L$(PKG)/csrc -lnsx_host -lnsx -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,'$$ORIGIN/../csrc'
 $(PKG)/host/navier_stokes2D: $(PKG)/host/main_cylinder.cpp $(PKG)/host/NavierStokes.hpp $(HOST_SO) $(DEV_SO)
 	$(CXX) $(CXXFLAGS) -DNSX_DIM=2 -o $@ $< -L$(PKG)/host -L$(PKG)/csrc -lnsx_host -lnsx -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,'$$ORIGIN/../csrc'
+$(PKG)/host/convergence: $(PKG)/host/main_convergence.cpp $(PKG)/host/Convergence.hpp $(HOST_SO) $(DEV_SO)
+	$(CXX) $(CXXFLAGS) -o $@ $< -L$(PKG)/host -L$(PKG)/csrc -lnsx_host -lnsx -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,'$$ORIGIN/../csrc'
 
 clean:
 	rm -f $(HOST_SO) $(DEV_SO) $(ORACLE_SO) $(MIRROR_BIN)

@@ -76,3 +76,22 @@ def test_convergence_study_on_device_matches_oracle():
         assert abs(rd["L2"] - ro["L2"]) < 1e-6 * ro["L2"] and abs(rd["H1"] - ro["H1"]) < 1e-6 * ro["H1"]
         assert np.abs(rd["solution"] - ro["solution"]).max() < 1e-6 * np.abs(ro["solution"]).max()
     assert np.log2(res_d[0]["L2"] / res_d[1]["L2"]) > 2.8
+
+
+def test_convergence_executable_matches_python_driver(tmp_path):
+    """The C++ mirror of main_convergence3D.cpp: same L2 / H1 errors as the Python driver on the same meshes, rates ~3 / ~2."""
+    import __graft_entry__ as ge
+    ge.build()
+    from navierstokes_project_nm4pde_amd import nsx
+    from navierstokes_project_nm4pde_amd.problem import run_convergence_case
+    exe = os.path.join(ROOT, "navierstokes_project_nm4pde_amd", "host", "convergence")
+    env = dict(os.environ, NSX_CONV_TOL="1e-9 1e-6")
+    out = subprocess.run([exe, "2", "4"], cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    rows = np.loadtxt(tmp_path / "convergence.csv", delimiter=",", skiprows=1)
+    assert rows.shape == (2, 3) and np.allclose(rows[:, 0], [1.0, 0.5])
+    for k, n in enumerate((2, 4)):
+        r = run_convergence_case(lambda d, t, nu, dt: nsx.Nsx(d, t, nu, dt), n, tol_abs=1e-9, inner_rtol=1e-6)
+        assert abs(rows[k, 1] - r["L2"]) < 1e-6 * r["L2"] and abs(rows[k, 2] - r["H1"]) < 1e-6 * r["H1"]
+    assert np.log2(rows[0, 1] / rows[1, 1]) > 2.8 and np.log2(rows[0, 2] / rows[1, 2]) > 1.8
+    assert "rate" in out.stdout and "Time taken to solve ENTIRE Navier Stokes problem" in out.stdout
