@@ -172,6 +172,7 @@ def main():
     base_level = 7
     if args.level is None:
         args.level = base_level if (world == 1 or args.scaling == "strong") else {2: 9, 4: 11, 8: 14}.get(world, int(round(7 * world ** (1 / 3.0))))
+    base_ranks, base_schur = args.ranks, args.schur_blocks
     if world > 1 and args.scaling == "weak":  # same rows per virtual rank on every GPU
         args.ranks *= world
         args.schur_blocks *= world
@@ -193,6 +194,8 @@ def main():
         if int(flag.item()) == 0:
             # last resort so that the scaling run still yields a line: N independent replicas of the whole problem (weak scaling)
             mode = "replicas (partitioned run failed on a rank: %s)" % (failed or "another rank")
+            # every GPU advances its own copy of the N = 1 workload
+            args.level, args.ranks, args.schur_blocks = base_level, base_ranks, base_schur
             mesh, dofs, tables = build_problem(args.level, args.ranks, 1, args.ordering)
             elapsed, stats, table = gpu_run(dofs, tables, args.steps, args.warmup, args.schur_blocks, local_rank,
                                             profile_steps=2 if rank == 0 else 0, barrier=barrier, rank=0, world=1)
