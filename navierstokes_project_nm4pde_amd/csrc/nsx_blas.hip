@@ -527,7 +527,9 @@ double read_scalar(nsx_handle *h, int slot) {
   read_scalars(h, slot, 1, &v);
   return v;
 }
-void read_scalars(nsx_handle *h, int slot0, int count, double *out) {
+// Enqueue the publication of scal[slot0 .. slot0+count) and return its sequence number; the host may enqueue more work
+// before it waits for the values (collect_published).  No other publication may be enqueued in between.
+unsigned long long publish_scalars(nsx_handle *h, int slot0, int count) {
   if (count > 64) NSX_THROW(NSX_ERR_ARG, "internal: read_scalars range too long");
   NbArgs args;
   for (int i = 0; i < count; ++i) {
@@ -538,9 +540,13 @@ void read_scalars(nsx_handle *h, int slot0, int count, double *out) {
   unsigned long long *flag_dev = (unsigned long long *)(h->pub_dev + N_SLOTS);
   hipLaunchKernelGGL(k_publish, dim3(count), dim3(256), 0, h->stream, slot0, count, args, h->red_partial.p, h->scal.p, h->pub_dev, flag_dev, seq,
                      h->pub_counter.p);
+  return seq;
+}
+void collect_published(nsx_handle *h, unsigned long long seq, int slot0, int count, double *out) {
   wait_published(h, seq);
   for (int i = 0; i < count; ++i) out[i] = h->pub_host[slot0 + i];
 }
+void read_scalars(nsx_handle *h, int slot0, int count, double *out) { collect_published(h, publish_scalars(h, slot0, count), slot0, count, out); }
 void write_scalar(nsx_handle *h, int slot, double v) {
   HIP_CHECK(hipStreamSynchronize(h->stream));
   h->scal_host[slot] = v;

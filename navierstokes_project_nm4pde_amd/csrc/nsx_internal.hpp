@@ -322,6 +322,8 @@ double *red_out(nsx_handle *h, int slot, int nb);
 void after_reduction(nsx_handle *h, int slot, int nb);
 double read_scalar(nsx_handle *h, int slot);
 void read_scalars(nsx_handle *h, int slot0, int count, double *out);
+unsigned long long publish_scalars(nsx_handle *h, int slot0, int count);  // asynchronous half of read_scalars
+void collect_published(nsx_handle *h, unsigned long long seq, int slot0, int count, double *out);
 void write_scalar(nsx_handle *h, int slot, double v);
 
 // solver (nsx_solve.hip)

@@ -183,11 +183,17 @@ static SolveResult cg(nsx_handle *h, const Op &A, double *x, const double *b, co
       A(hv.p(), d.p());
       v_dot(h, n, d.p(), hv.p(), S_DH);
       cg_update(h, n.n, x, d.p(), g.p(), hv.p(), gh, S_DH, S_RES);  // alpha = gh / (d.h); x += alpha d; g += alpha h; res = |g|
-      r = std::sqrt(std::fabs(read_scalar(h, S_RES)));
+      // The residual travels to the host while the GPU already applies the preconditioner of the NEXT iteration
+      // (h = P g and g.h only touch temporaries): the host round trip hides behind that kernel instead of idling the
+      // device; the work is wasted once per solve, in the iteration that converges.
+      const unsigned long long seq = publish_scalars(h, S_RES, 1);
+      apply_P_dot(hv.p(), g.p(), gh_new);
+      double res2;
+      collect_published(h, seq, S_RES, 1, &res2);
+      r = std::sqrt(std::fabs(res2));
       res.last = r;
       conv = sc_check(it, r, tol, maxiter);
       if (conv != 0) break;
-      apply_P_dot(hv.p(), g.p(), gh_new);
       cg_direction(h, n.n, d.p(), hv.p(), gh_new, gh);  // beta = gh_new / gh_old ; d = beta d - h
       std::swap(gh, gh_new);
     }
