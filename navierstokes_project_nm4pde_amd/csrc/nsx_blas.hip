@@ -377,7 +377,8 @@ static void wait_published(nsx_handle *h, unsigned long long seq) {
 }
 
 // out[0..dim) = h(i), out[dim] = |w|^2 after the sweep.  Returns true when w was also normalised (only if asked to).
-bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int slot0, bool normalize, double *out) {
+bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int slot0, bool normalize, double *out,
+           const std::function<void()> *after_launch) {
   const int n = sp.n;
   if (!h->comm) mgs_setup(h);
   const int nwg = std::max(1, std::min(h->mgs_max_wg, cdiv(n, 256 * 4)));
@@ -415,6 +416,9 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
     h->mgs_parity ^= 1;
     for (int i = 0; i <= dim; ++i) h->slot_nb[slot0 + i] = 0;
   }
+  // w is final (and normalised) once the kernel has run: work that only depends on it may be enqueued before the host
+  // has the coefficients
+  if (normalize && after_launch) (*after_launch)();
   wait_published(h, seq);
   for (int i = 0; i <= dim; ++i) out[i] = h->pub_host[slot0 + i];
   return normalize;

@@ -19,6 +19,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "../../include/nsx.h"
@@ -313,7 +314,10 @@ void v_add_and_dot(nsx_handle *h, Span n, double *d, double a, int aslot, const 
                                                                                             // d += a*scal[aslot]*v ; scal[slot] = d.w
 // modified Gram-Schmidt sweep of SolverGMRES (w against v_0..v_{dim-1}): out[i] = h(i), out[dim] = |w|^2 afterwards (host
 // values; scal[slot0+i] holds them too).  normalize: also w *= 1/|w| if the sweep runs as one launch; returns whether it did.
-bool v_mgs(nsx_handle *h, Span n, double *w, int dim, double *const *vs, int slot0, bool normalize, double *out);
+// after_launch (optional) runs between the launch and the wait for the coefficients, only when the sweep is one launch
+// AND normalises w: the caller may enqueue work that depends on the finished w alone.
+bool v_mgs(nsx_handle *h, Span n, double *w, int dim, double *const *vs, int slot0, bool normalize, double *out,
+           const std::function<void()> *after_launch = nullptr);
 void v_axpy_multi(nsx_handle *h, Span n, double *x, int k, double *const *vs, const double *coef_host);
 void finalize_slots(nsx_handle *h, int slot0, int count);
 // for kernels that leave nb <= 512 per-workgroup partial sums of a scalar themselves: where to put them, and the

@@ -84,7 +84,9 @@ static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b,
   int accumulated = 0, state = 0, dim = 0;
   bool re_orth = false;
   double *v = vec(0), *p = vec(N_TMP - 1);
+  bool ahead = false;
   do {
+    ahead = false;
     A(p, x);
     v_sadd(h, n, p, -1., 1., b);
     P(v, p);
@@ -99,7 +101,8 @@ static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b,
     for (int inner = 0; inner < N_TMP - 2 && state == 0; ++inner) {
       ++accumulated;
       double *vv = vec(inner + 1);
-      A(p, vec(inner));
+      if (!ahead) A(p, vec(inner));  // already enqueued behind the previous iteration's Gram-Schmidt sweep
+      ahead = false;
       P(vv, p);
       dim = inner + 1;
       // modified Gram-Schmidt, h(i) = vv . v_i after removing the previous components (add_and_dot chain)
@@ -108,7 +111,16 @@ static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b,
       double *basis[N_TMP];
       for (int i = 0; i < dim; ++i) basis[i] = vec(i);
       // the sweep can normalise vv itself (vv *= 1./s below) when no second sweep can follow it
-      bool normalized = v_mgs(h, n, vv, dim, basis, S_H, !re_orth && !consider, hh);
+      // The sweep leaves the next basis vector complete; A * vv of the NEXT iteration is enqueued right behind it, so the
+      // device does not idle while the coefficients travel to the host and the Givens rotations are updated.  Wasted
+      // once per solve (the iteration that converges); p is a temporary.
+      const std::function<void()> next_A = [&]() {
+        if (inner + 1 < N_TMP - 2) {
+          A(p, vv);
+          ahead = true;
+        }
+      };
+      bool normalized = v_mgs(h, n, vv, dim, basis, S_H, !re_orth && !consider, hh, &next_A);
       double s = std::sqrt(hh[dim]);
       if (consider) {
         const double norm_vv_start = std::sqrt(read_scalar(h, S_NRM));
