@@ -268,7 +268,7 @@ __device__ __forceinline__ double mgs_block_sum(double v, double *sh) {
 
 __global__ __launch_bounds__(256) void k_mgs(int n, int split, int gap, double *__restrict__ w, MgsArgs V, int dim,
                                              unsigned long long *box, unsigned long long *box_next, int reset_wg, int reset_steps,
-                                             double *__restrict__ scal_out, int *err, int normalize, double *pub_vals,
+                                             double *__restrict__ scal_out, int *err, int normalize, int consider, double *pub_vals,
                                              unsigned long long *pub_flag, unsigned long long seq) {
   __shared__ double sh[2][4];  // two buffers: a wave may start the next sum while a slower one still reads this one
   __shared__ unsigned long long bc;
@@ -289,17 +289,22 @@ __global__ __launch_bounds__(256) void k_mgs(int n, int split, int gap, double *
     vc[k] = idx[k] >= 0 ? V.v[0][idx[k]] : 0.0;
     vn[k] = 0.0;
   }
-  for (int s = 0; s <= dim; ++s) {
+  // consider: SolverGMRES' re-orthogonalisation test (every 5th inner iteration) needs |w| BEFORE the sweep: one more link
+  // in front (mailbox row dim + 1), and the decision whether w may be normalised is taken here exactly as the host takes it
+  double norm0_sq = 0.0;
+  for (int s = consider ? -1 : 0; s <= dim; ++s) {
+    const bool pre = s < 0;
+    const int ri = pre ? dim + 1 : s;
     double acc = 0.0;
 #pragma unroll
-    for (int k = 0; k < MGS_E; ++k) acc += wv[k] * (s < dim ? vc[k] : wv[k]);
-    if (s + 1 < dim) {  // the next basis vector is on its way while the sums are exchanged
+    for (int k = 0; k < MGS_E; ++k) acc += wv[k] * ((!pre && s < dim) ? vc[k] : wv[k]);
+    if (!pre && s + 1 < dim) {  // the next basis vector is on its way while the sums are exchanged
       const double *__restrict__ vp = V.v[s + 1];
 #pragma unroll
       for (int k = 0; k < MGS_E; ++k) vn[k] = idx[k] >= 0 ? vp[idx[k]] : 0.0;
     }
     const double part = mgs_block_sum(acc, sh[0]);
-    unsigned long long *row = box + (size_t)s * MGS_MAX_WG;
+    unsigned long long *row = box + (size_t)ri * MGS_MAX_WG;
     if (threadIdx.x == 0) __hip_atomic_store(row + wg, mgs_bits(part), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // workgroup 0 collects the partial sums, adds them in a fixed order and publishes the total; the others wait for
     // that one word (letting every workgroup read all mailboxes saves a trip through memory on paper but measured
@@ -310,14 +315,18 @@ __global__ __launch_bounds__(256) void k_mgs(int n, int split, int gap, double *
       if ((int)threadIdx.x + 256 < nwg) b = __longlong_as_double((long long)mgs_wait(row + threadIdx.x + 256, err));
       const double tot = mgs_block_sum(a + b, sh[1]);
       if (threadIdx.x == 0) {
-        scal_out[s] = tot;
-        __hip_atomic_store(total + s, mgs_bits(tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        tots[s] = tot;
+        scal_out[ri] = tot;
+        __hip_atomic_store(total + ri, mgs_bits(tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tots[ri] = tot;
       }
     }
-    if (threadIdx.x == 0) bc = mgs_wait(total + s, err);
+    if (threadIdx.x == 0) bc = mgs_wait(total + ri, err);
     __syncthreads();
     const double hs = __longlong_as_double((long long)bc);
+    if (pre) {
+      norm0_sq = hs;
+      continue;
+    }
     if (s < dim) {
       const double alpha = -1.0 * hs;
 #pragma unroll
@@ -327,7 +336,9 @@ __global__ __launch_bounds__(256) void k_mgs(int n, int split, int gap, double *
       }
     } else if (normalize) {  // vv *= 1. / s with s = sqrt(|vv|^2), skipped for s == 0 (SolverGMRES)
       const double nrm = sqrt(hs);
-      if (nrm != 0.0) {
+      // no normalisation if the test asks for a second sweep: s <= 10 |vv_start| sqrt(eps), sqrt(eps) = 2^-26
+      const bool second_sweep = consider && !(nrm > 10. * sqrt(norm0_sq) * 1.4901161193847656e-08);
+      if (nrm != 0.0 && !second_sweep) {
         const double inv = 1. / nrm;
 #pragma unroll
         for (int k = 0; k < MGS_E; ++k) wv[k] = inv * wv[k];
@@ -338,7 +349,7 @@ __global__ __launch_bounds__(256) void k_mgs(int n, int split, int gap, double *
   // stores are acknowledged (vmcnt) before the flag goes out; a system-scope release would also write back the whole L2.
   if (wg == 0) {
     __syncthreads();
-    if ((int)threadIdx.x <= dim) __hip_atomic_store(pub_vals + threadIdx.x, tots[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((int)threadIdx.x <= dim + (consider ? 1 : 0)) __hip_atomic_store(pub_vals + threadIdx.x, tots[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(pub_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -378,16 +389,17 @@ static void wait_published(nsx_handle *h, unsigned long long seq) {
 
 // out[0..dim) = h(i), out[dim] = |w|^2 after the sweep.  Returns true when w was also normalised (only if asked to).
 bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int slot0, bool normalize, double *out,
-           const std::function<void()> *after_launch) {
+           const std::function<void()> *after_launch, bool consider) {
   const int n = sp.n;
   if (!h->comm) mgs_setup(h);
   const int nwg = std::max(1, std::min(h->mgs_max_wg, cdiv(n, 256 * 4)));
-  if (h->comm || h->mgs_max_wg == 0 || dim + 1 > MGS_STEPS || (int64_t)nwg * 256 * MGS_E < n) {
+  if (h->comm || h->mgs_max_wg == 0 || dim + 2 > MGS_STEPS || (int64_t)nwg * 256 * MGS_E < n) {
     // one launch per link: the distributed solve needs an all-reduce after every dot product
+    if (consider) v_dot(h, sp, w, w, slot0 + dim + 1);
     v_dot(h, sp, w, vs[0], slot0);
     for (int i = 1; i < dim; ++i) v_add_and_dot(h, sp, w, -1.0, slot0 + i - 1, vs[i - 1], vs[i], slot0 + i);
     v_add_and_dot(h, sp, w, -1.0, slot0 + dim - 1, vs[dim - 1], w, slot0 + dim);
-    read_scalars(h, slot0, dim + 1, out);
+    read_scalars(h, slot0, dim + 1 + (consider ? 1 : 0), out);
     return false;
   }
   const unsigned long long seq = ++h->pub_seq;
@@ -396,13 +408,13 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
     MgsArgs V;
     for (int i = 0; i < dim; ++i) V.v[i] = vs[i];
     for (int i = dim; i < MGS_STEPS; ++i) V.v[i] = nullptr;
-    int n_ = n, split = sp.split, gap = sp.gap, dim_ = dim, norm_ = normalize ? 1 : 0;
+    int n_ = n, split = sp.split, gap = sp.gap, dim_ = dim, norm_ = normalize ? 1 : 0, consider_ = consider ? 1 : 0;
     unsigned long long *box = h->mgs_box.p + (size_t)h->mgs_parity * MGS_REGION, *box_next = h->mgs_box.p + (size_t)(1 - h->mgs_parity) * MGS_REGION;
     double *sout = h->scal.p + slot0, *pub_vals = h->pub_dev + slot0;
     unsigned long long *pub_flag = (unsigned long long *)(h->pub_dev + N_SLOTS), seq_ = seq;
     int *err = (int *)(h->pub_dev + N_SLOTS + 2);  // mapped host word, checked by wait_published
     int reset_wg = h->mgs_used_wg[1 - h->mgs_parity], reset_steps = h->mgs_used_steps[1 - h->mgs_parity];
-    void *args[] = {&n_, &split, &gap, &w, &V, &dim_, &box, &box_next, &reset_wg, &reset_steps, &sout, &err, &norm_, &pub_vals, &pub_flag, &seq_};
+    void *args[] = {&n_, &split, &gap, &w, &V, &dim_, &box, &box_next, &reset_wg, &reset_steps, &sout, &err, &norm_, &consider_, &pub_vals, &pub_flag, &seq_};
     // Co-residency: the grid never exceeds what the device holds at once (mgs_setup), the stream is in-order and nothing else
     // runs on this queue, so a plain launch places every workgroup at once; hipLaunchCooperativeKernel guarantees it but
     // goes through the device-wide cooperative queue, which costs ~20 us of cross-queue synchronisation per launch.
@@ -411,17 +423,19 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
     if (coop) HIP_CHECK(hipLaunchCooperativeKernel((const void *)k_mgs, dim3(nwg), dim3(256), args, 0, h->stream));
     else HIP_CHECK(hipLaunchKernel((const void *)k_mgs, dim3(nwg), dim3(256), args, 0, h->stream));
     h->mgs_used_wg[h->mgs_parity] = nwg;
-    h->mgs_used_steps[h->mgs_parity] = dim + 1;
+    h->mgs_used_steps[h->mgs_parity] = dim + 2;
     h->mgs_used_wg[1 - h->mgs_parity] = h->mgs_used_steps[1 - h->mgs_parity] = 0;
     h->mgs_parity ^= 1;
-    for (int i = 0; i <= dim; ++i) h->slot_nb[slot0 + i] = 0;
+    for (int i = 0; i <= dim + 1; ++i) h->slot_nb[slot0 + i] = 0;
   }
   // w is final (and normalised) once the kernel has run: work that only depends on it may be enqueued before the host
   // has the coefficients
-  if (normalize && after_launch) (*after_launch)();
+  if (normalize && !consider && after_launch) (*after_launch)();
   wait_published(h, seq);
-  for (int i = 0; i <= dim; ++i) out[i] = h->pub_host[slot0 + i];
-  return normalize;
+  for (int i = 0; i <= dim + (consider ? 1 : 0); ++i) out[i] = h->pub_host[slot0 + i];
+  if (!normalize) return false;
+  // the kernel's own decision, recomputed from the same two numbers
+  return !consider || std::sqrt(out[dim]) > 10. * std::sqrt(out[dim + 1]) * 1.4901161193847656e-08;
 }
 
 // ---- element-wise

@@ -317,7 +317,9 @@ void v_add_and_dot(nsx_handle *h, Span n, double *d, double a, int aslot, const 
 // after_launch (optional) runs between the launch and the wait for the coefficients, only when the sweep is one launch
 // AND normalises w: the caller may enqueue work that depends on the finished w alone.
 bool v_mgs(nsx_handle *h, Span n, double *w, int dim, double *const *vs, int slot0, bool normalize, double *out,
-           const std::function<void()> *after_launch = nullptr);
+           const std::function<void()> *after_launch = nullptr, bool consider = false);
+// consider: also out[dim+1] = |w|^2 BEFORE the sweep (SolverGMRES' re-orthogonalisation test); a single-launch sweep then
+// normalises w only if the test does not ask for a second sweep.
 void v_axpy_multi(nsx_handle *h, Span n, double *x, int k, double *const *vs, const double *coef_host);
 void finalize_slots(nsx_handle *h, int slot0, int count);
 // for kernels that leave nb <= 512 per-workgroup partial sums of a scalar themselves: where to put them, and the

@@ -80,7 +80,7 @@ static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b,
     return tmp[i]->p();
   };
   double H[N_TMP][N_TMP - 1];
-  double gamma[N_TMP], ci[N_TMP - 1], si[N_TMP - 1], hh[N_TMP + 1], h2[N_TMP + 1];
+  double gamma[N_TMP], ci[N_TMP - 1], si[N_TMP - 1], hh[N_TMP + 2], h2[N_TMP + 2];
   int accumulated = 0, state = 0, dim = 0;
   bool re_orth = false;
   double *v = vec(0), *p = vec(N_TMP - 1);
@@ -107,7 +107,6 @@ static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b,
       dim = inner + 1;
       // modified Gram-Schmidt, h(i) = vv . v_i after removing the previous components (add_and_dot chain)
       const bool consider = !re_orth && (inner % 5 == 4);
-      if (consider) v_dot(h, n, vv, vv, S_NRM);
       double *basis[N_TMP];
       for (int i = 0; i < dim; ++i) basis[i] = vec(i);
       // the sweep can normalise vv itself (vv *= 1./s below) when no second sweep can follow it
@@ -120,10 +119,10 @@ static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b,
           ahead = true;
         }
       };
-      bool normalized = v_mgs(h, n, vv, dim, basis, S_H, !re_orth && !consider, hh, &next_A);
+      bool normalized = v_mgs(h, n, vv, dim, basis, S_H, !re_orth, hh, &next_A, consider);
       double s = std::sqrt(hh[dim]);
       if (consider) {
-        const double norm_vv_start = std::sqrt(read_scalar(h, S_NRM));
+        const double norm_vv_start = std::sqrt(hh[dim + 1]);  // |vv| before the sweep, computed inside it
         if (!(s > 10. * norm_vv_start * std::sqrt(2.220446049250313e-16))) re_orth = true;
       }
       if (re_orth) {
