@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 # scope name used by the library's HIP-event timer -> kernel symbol in rocprofv3 output
-KERNEL_OF = {"mgs_sweep": "nsx::k_mgs", "add_and_dot": "void nsx::k_reduce<1>", "dot": "void nsx::k_reduce<0>", "spmv_F": "void nsx::k_spmv_vel<3, 16, false>",
+KERNEL_OF = {"mgs_sweep": "nsx::k_mgs", "add_and_dot": "void nsx::k_reduce<1>", "dot": "void nsx::k_reduce<0>", "spmv_F": "void nsx::k_spmv_blocked<3, 16>",
              "ilu_solve_F": "void nsx::k_ilu_solve_packed<3, 8, 8>", "ilu_solve_S": "void nsx::k_ilu_solve_packed<1, 32, 8>",
              "axpby": "nsx::k_axpby", "spmv_S": "void nsx::k_spmv_csr<32>"}
 
