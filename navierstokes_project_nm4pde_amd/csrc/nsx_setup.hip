@@ -586,7 +586,7 @@ void setup_mesh(nsx_handle *h, int n_cells, int n_cells1, const double *cell_coo
   h->gPM.host = build_graph(n_cells, np1, c1, h->NP_loc, np1, c1, h->NP_loc);
   truncate_rows(h->gPM.host, h->NP);
   upload_csr(h, h->gA, true);
-  build_blocked(h, h->gA.host, 128, h->blkA);
+  build_blocked(h, h->gA.host, getenv("NSX_SPMV_R") ? std::max(16, std::min(256, atoi(getenv("NSX_SPMV_R")))) : 128, h->blkA);
   upload_csr(h, h->gG, false);
   upload_csr(h, h->gB, false);
   upload_csr(h, h->gPM, true);
