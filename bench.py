@@ -59,7 +59,9 @@ def gpu_run(dofs, tables, steps, warmup, schur_blocks, device, profile_steps=2, 
     from navierstokes_project_nm4pde_amd import nsx
     from navierstokes_project_nm4pde_amd.problem import InletVelocity, cylinder_boundary_values
     nu, dt = 1e-3, 2e-4
-    dev = nsx.Nsx(dofs, tables, nu, dt, device=device, rank=rank, world=world, comm="rccl")
+    # NSX_BENCH_COMM=callbacks (development only): host-callback exchange over torch.distributed instead of RCCL, which lets
+    # the N > 1 control flow be rehearsed with several ranks on ONE card
+    dev = nsx.Nsx(dofs, tables, nu, dt, device=device, rank=rank, world=world, comm=os.environ.get("NSX_BENCH_COMM", "rccl"))
     if schur_blocks and schur_blocks < dofs.n_subdomains:
         # coarser ILU blocks for the Schur matrix: unions of consecutive virtual ranks (of this GPU)
         n_sub = dofs.n_subdomains // world
@@ -160,7 +162,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")
+        dist.init_process_group(os.environ.get("NSX_BENCH_PG", "nccl"))  # "gloo" only for the one-card rehearsal
         def barrier():
             dist.barrier()
             torch.cuda.synchronize()
@@ -189,7 +191,7 @@ def main():
     if world > 1:
         # did every rank get through the partitioned run?  (torch's own process group, independent of libnsx's communicator)
         import torch.distributed as dist
-        flag = torch.tensor([0 if failed else 1], dtype=torch.int32, device="cuda")
+        flag = torch.tensor([0 if failed else 1], dtype=torch.int32, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
             # last resort so that the scaling run still yields a line: N independent replicas of the whole problem (weak scaling)
@@ -201,7 +203,7 @@ def main():
                                             profile_steps=2 if rank == 0 else 0, barrier=barrier, rank=0, world=1)
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     if rank != 0:
