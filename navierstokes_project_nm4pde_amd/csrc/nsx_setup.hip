@@ -399,16 +399,24 @@ static void default_ranks(nsx_handle *h) {
   h->sblk_h.clear();
 }
 
+// The rank tables changed: the Dirichlet scan needs them at once, the ILU schedules (seconds of host work at 1 M DoF) are
+// rebuilt when a preconditioner is next initialised, so nsx_set_mesh + nsx_set_ranks + nsx_set_schur_blocks build them once.
 static void refresh_rank_products(nsx_handle *h) {
   h->rank_u.upload(h->rank_u_h, h->stream);
   h->dbar.alloc(h->rank_u_h.size() - 1);
+  h->sched_dirty = true;
+  h->prec_ready = false;
+}
+
+void ensure_schedules(nsx_handle *h) {
+  if (!h->sched_dirty) return;
   const int lwF = getenv("NSX_LW_F") ? atoi(getenv("NSX_LW_F")) : 8, lwS = getenv("NSX_LW_S") ? atoi(getenv("NSX_LW_S")) : 32;
   const int bpwF = getenv("NSX_BPW_F") ? atoi(getenv("NSX_BPW_F")) : 1, bpwS = getenv("NSX_BPW_S") ? atoi(getenv("NSX_BPW_S")) : 1;
   const bool wideF = !(getenv("NSX_WIDE") && atoi(getenv("NSX_WIDE")) == 0);
   setup_ilu_schedule(h, h->gA.host, h->rank_u_h, h->schedF, lwF, bpwF, false, wideF && h->dim > 1);
   const bool denseS = !(getenv("NSX_DENSE_S") && atoi(getenv("NSX_DENSE_S")) == 0);
   setup_ilu_schedule(h, h->gS.host, h->sblk_h.empty() ? h->rank_p_h : h->sblk_h, h->schedS, lwS, bpwS, denseS);
-  h->prec_ready = false;
+  h->sched_dirty = false;
 }
 
 }  // namespace nsx

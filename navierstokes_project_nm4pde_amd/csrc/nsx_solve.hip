@@ -221,6 +221,7 @@ static double norm2(nsx_handle *h, Span n, const double *v) {
 
 // ------------------------------------------------------------------ preconditioners
 void prec_initialize(nsx_handle *h, int type) {
+  ensure_schedules(h);
   if (!h->assembled) NSX_THROW(NSX_ERR_ARG, "assemble before initialising a preconditioner");
   HIP_CHECK(hipSetDevice(h->prm.device));
   const int n_u = h->n_u;
