@@ -112,7 +112,8 @@ int nsx_set_rhs(nsx_handle *h, const double *system_rhs);
 /* ---- the hot path ---- */
 
 /* NavierStokes::assemble(time) without its Dirichlet block (reference NavierStokes3D.cpp:163-324):
- * mass/deltat, nu*stiffness, convection(u_n) (+Temam), -B^T / B, pressure mass; system = blocks + M + C + K; rhs. */
+ * mass/deltat, nu*stiffness, convection(u_n) (+Temam), -B^T / B, pressure mass; system = blocks + M + C + K; rhs.
+ * As the run's set-up step it also builds the ILU schedules for the current rank / Schur block tables (host work, once). */
 int nsx_assemble(nsx_handle *h, int flags);
 /* NavierStokes::assemble_time_step(time) without its Dirichlet block (reference NavierStokes3D.cpp:361-512):
  * new convection(u_n) and rhs; system = system - C_old + C_new. */
