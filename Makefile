@@ -4,16 +4,17 @@ CXX      ?= g++
 CC       ?= gcc
 HIPCC    ?= /opt/rocm/bin/hipcc
 CXXFLAGS := -O2 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter
-CFLAGS   := -O3 -march=x86-64-v3 -std=c99 -fPIC -Wall -Wextra -ffp-contract=off
+CFLAGS   := -O3 -march=x86-64-v3 -std=c99 -fPIC -Wall -Wextra -Wno-unknown-pragmas -ffp-contract=off
 HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -Wall -Wno-unused-parameter
 
 HOST_SO   := $(PKG)/host/libnsx_host.so
 DEV_SO    := $(PKG)/csrc/libnsx.so
 ORACLE_SO := oracle/liboracle.so
+ORACLE_MT_SO := oracle/liboracle_mt.so
 
 all: host oracle device mirror
 host: $(HOST_SO)
-oracle: $(ORACLE_SO)
+oracle: $(ORACLE_SO) $(ORACLE_MT_SO)
 device: $(DEV_SO)
 
 $(HOST_SO): $(PKG)/host/frontend.cpp $(PKG)/host/graph.hpp include/nsx_host.h
@@ -21,6 +22,9 @@ $(HOST_SO): $(PKG)/host/frontend.cpp $(PKG)/host/graph.hpp include/nsx_host.h
 
 $(ORACLE_SO): oracle/nsx_oracle.c oracle/nsx_oracle.h
 	$(CC) $(CFLAGS) -shared -o $@ oracle/nsx_oracle.c -lm
+# the same restatement with its rank-parallel loops on OpenMP threads: bench.py's all-cores CPU baseline
+$(ORACLE_MT_SO): oracle/nsx_oracle.c oracle/nsx_oracle.h
+	$(CC) $(CFLAGS) -fopenmp -shared -o $@ oracle/nsx_oracle.c -lm
 
 DEV_SRC := $(wildcard $(PKG)/csrc/*.hip)
 DEV_HDR := $(wildcard $(PKG)/csrc/*.hpp) include/nsx.h $(PKG)/host/graph.hpp
@@ -38,5 +42,5 @@ $(PKG)/host/convergence: $(PKG)/host/main_convergence.cpp $(PKG)/host/Convergenc
 	$(CXX) $(CXXFLAGS) -o $@ $< -L$(PKG)/host -L$(PKG)/csrc -lnsx_host -lnsx -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,'$$ORIGIN/../csrc'
 
 clean:
-	rm -f $(HOST_SO) $(DEV_SO) $(ORACLE_SO) $(MIRROR_BIN)
+	rm -f $(HOST_SO) $(DEV_SO) $(ORACLE_SO) $(ORACLE_MT_SO) $(MIRROR_BIN)
 .PHONY: all host oracle device mirror clean

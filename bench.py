@@ -9,17 +9,23 @@ region starts; VTU output and forces are excluded.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--level L] [--ranks R] [--schur-blocks S]
 
-For N > 1 the driver launches one process per GPU with torch.distributed.run.  ONE mesh is partitioned over the N
-GPUs (owned rows + ghost layers per rank, RCCL halo exchange of ghost DoFs inside every SpMV, RCCL all-reduce of every
-dot product, per-rank ILU(0) exactly as the reference's MPI run).  Default `--scaling weak`: the mesh grows with N so
-that every GPU keeps ~1M DoF (N = 8 gives the ~10M-DoF configuration of BASELINE.json configs[3]) and `value` is the
-whole-job rate normalised to the N = 1 workload, value = time-steps/s x (DoF_N / DoF_1), i.e. DoF-steps/s in units of
-the 1.09M-DoF problem; `--scaling strong` keeps the 1.09M-DoF mesh for every N (latency bound: one 8-byte all-reduce
-per Gram-Schmidt coefficient).  Prints ONE JSON line on rank 0.
+N > 1: one process per GPU under torch.distributed.run (the driver's launch line); `python bench.py --gpus N` without
+that launcher starts it as a child process.  ONE mesh is partitioned over the N GPUs (owned rows + ghost layers per
+rank, RCCL halo exchange of ghost DoFs inside every SpMV, RCCL all-reduce of every dot product, per-rank ILU(0) exactly
+as the reference's MPI run).  The headline `value` is WEAK scaling: the mesh grows with N so that every GPU keeps ~1M
+DoF (N = 8 gives the ~10M-DoF configuration of BASELINE.json configs[3]); value = time-steps/s x (DoF_N / DoF_1), i.e.
+DoF-steps/s in units of the 1.09M-DoF problem.  The same invocation also partitions the 1.09M-DoF mesh itself over the N
+GPUs and reports that STRONG-scaling figure under "strong" (latency bound: one 8-byte all-reduce per Gram-Schmidt
+coefficient).  A rank that fails makes the whole job exit non-zero; there is no fallback mode.
+
+Other modes (not the driver's): --cpu-only (the cpu_baseline leg alone), --layout-table FILE (iteration counts of the
+preconditioner for R in {1, 8, 4096} x {first_touch, colour} at full size; its committed result is embedded in every
+bench line as "preconditioner_layouts").  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -27,25 +33,31 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+BASE_LEVEL, BASE_DOFS = 7, 1089643  # the N = 1 workload: level-7 cylinder mesh
+PMC_PROFILE = "profiles/r02_pmc_fetch_write_per_kernel.json"
+LAYOUT_PROFILE = "profiles/r02_layout_iterations.json"
+NU, DT = 1e-3, 2e-4
 
 # scope name used by the library's HIP-event timer -> kernel symbol in rocprofv3 output
 KERNEL_OF = {"mgs_sweep": "nsx::k_mgs", "add_and_dot": "void nsx::k_reduce<1>", "dot": "void nsx::k_reduce<0>", "spmv_F": "void nsx::k_spmv_blocked<3, 16>",
-             "ilu_solve_F": "void nsx::k_ilu_solve_packed<3, 8, 8>", "ilu_solve_S": "void nsx::k_ilu_solve_packed<1, 32, 8>",
-             "axpby": "nsx::k_axpby", "spmv_S": "void nsx::k_spmv_csr<32>"}
+             "ilu_solve_F": "void nsx::k_ilu_solve_packed<3, 8, 8>", "ilu_solve_S": "nsx::k_ilu_apply_dense",
+             "axpby": "nsx::k_axpby", "spmv_S": "void nsx::k_spmv_csr<32>", "cg_S": "nsx::k_cg_schur"}
 
 
 def pmc_traffic(scope):
-    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same command (FETCH_SIZE and
+    """HBM-side bytes per launch from the COMMITTED rocprofv3 --pmc passes of this same command (FETCH_SIZE and
     WRITE_SIZE in separate passes, values in KiB; gfx950 FETCH_SIZE counts 64 B per 128-B request, so it is doubled:
-    /opt/skills/guides/MI355X_MICROARCH.md section HBM).  None when no profile is committed for the kernel."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_fetch_write_per_kernel.json")  # tools/pmc_summary.py
-    try:
-        with open(path) as f:
-            tab = json.load(f)
-        e = tab[KERNEL_OF[scope]]
-        return (2.0 * e["FETCH_SIZE_KB_avg"] + e["WRITE_SIZE_KB_avg"]) * 1024.0
-    except (OSError, KeyError, ValueError):
-        return None
+    /opt/skills/guides/MI355X_MICROARCH.md section HBM).  A constant read from a profile, not measured in this run (PMC
+    counters need rocprofv3 around the process); None when no profile is committed for the kernel."""
+    for rel in (PMC_PROFILE, "profiles/r01_pmc_fetch_write_per_kernel.json"):
+        try:
+            with open(os.path.join(ROOT, rel)) as f:
+                tab = json.load(f)
+            e = tab[KERNEL_OF[scope]]
+            return (2.0 * e["FETCH_SIZE_KB_avg"] + e["WRITE_SIZE_KB_avg"]) * 1024.0, rel
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
 def build_problem(level, ranks, world=1, ordering="colour"):
@@ -54,86 +66,204 @@ def build_problem(level, ranks, world=1, ordering="colour"):
     return mesh, DoFs(mesh, ordering), Tables(3)
 
 
-def gpu_run(dofs, tables, steps, warmup, schur_blocks, device, profile_steps=2, barrier=None, rank=0, world=1):
+def transfer_state(src_dofs, x, dst_dofs):
+    """The same finite-element function in another DoF numbering of the same mesh (other rank count / node order):
+    nodes are matched through their support points, which are bitwise equal in both numberings."""
+    import numpy as np
+    dim = src_dofs.dim
+    out = np.empty_like(x)
+    for lo, hi, stride in ((0, src_dofs.n_u, dim), (src_dofs.n_u, src_dofs.n_dofs, 1)):
+        ps, pd = src_dofs.support_points[lo:hi:stride], dst_dofs.support_points[lo:hi:stride]
+        ks, kd = np.lexsort(ps.T[::-1]), np.lexsort(pd.T[::-1])
+        assert (ps[ks] == pd[kd]).all(), "the two DoF tables do not describe the same mesh"
+        perm = np.empty(len(ks), dtype=np.int64)  # node of src that sits at dst node i
+        perm[kd] = ks
+        for c in range(stride):
+            out[lo + c:hi:stride] = x[lo + c:hi:stride][perm]
+    return out
+
+
+def schur_block_table(dofs, schur_blocks, rank=0, world=1):
+    """coarser ILU blocks for the Schur matrix: unions of consecutive virtual ranks (of this GPU)"""
+    import numpy as np
+    n_sub = dofs.n_subdomains // world
+    mine = dofs.owned_p_ptr[rank * n_sub:(rank + 1) * n_sub + 1]
+    stride = max(1, n_sub // max(1, schur_blocks // world))
+    ptr = list(mine[::stride])
+    if ptr[-1] != mine[-1]:
+        ptr.append(mine[-1])
+    return np.array(ptr, dtype=np.int32)
+
+
+def gpu_run(dofs, tables, steps, warmup, schur_blocks, device, profile_steps=5, barrier=None, rank=0, world=1, want_state=False):
+    """first step + warmup + `steps` timed steps (+ a separate per-kernel HIP-event pass).  The handle is closed on every
+    path: a failure must not leave a communicator or a second copy of the problem behind."""
     import numpy as np
     from navierstokes_project_nm4pde_amd import nsx
     from navierstokes_project_nm4pde_amd.problem import InletVelocity, cylinder_boundary_values
-    nu, dt = 1e-3, 2e-4
     # NSX_BENCH_COMM=callbacks (development only): host-callback exchange over torch.distributed instead of RCCL, which lets
     # the N > 1 control flow be rehearsed with several ranks on ONE card
-    dev = nsx.Nsx(dofs, tables, nu, dt, device=device, rank=rank, world=world, comm=os.environ.get("NSX_BENCH_COMM", "rccl"))
-    if schur_blocks and schur_blocks < dofs.n_subdomains:
-        # coarser ILU blocks for the Schur matrix: unions of consecutive virtual ranks (of this GPU)
-        n_sub = dofs.n_subdomains // world
-        mine = dofs.owned_p_ptr[rank * n_sub:(rank + 1) * n_sub + 1]
-        stride = max(1, n_sub // max(1, schur_blocks // world))
-        ptr = list(mine[::stride])
-        if ptr[-1] != mine[-1]:
-            ptr.append(mine[-1])
-        dev.set_schur_blocks(np.array(ptr, dtype=np.int32))
-    inlet = InletVelocity(3)  # test case 2, u_m = 9 (reference NavierStokes3D.hpp:37,80)
-    dev.set_solution(np.zeros(dofs.n_dofs))  # u_0 = 0 (reference NavierStokes3D.hpp:200)
-    t = 0.0
-    stats = []
+    dev = nsx.Nsx(dofs, tables, NU, DT, device=device, rank=rank, world=world, comm=os.environ.get("NSX_BENCH_COMM", "rccl"))
+    try:
+        if schur_blocks and schur_blocks < dofs.n_subdomains:
+            dev.set_schur_blocks(schur_block_table(dofs, schur_blocks, rank, world))
+        inlet = InletVelocity(3)  # test case 2, u_m = 9 (reference NavierStokes3D.hpp:37,80)
+        dev.set_solution(np.zeros(dofs.n_dofs))  # u_0 = 0 (reference NavierStokes3D.hpp:200)
+        t = 0.0
+        stats = []
 
-    def one_step(first):
-        nonlocal t
-        t += dt
-        if first:
-            dev.assemble(nsx.TEMAM)
-        else:
-            dev.assemble_time_step(0)
-        bd, bv = cylinder_boundary_values(dofs, inlet, t)
-        dev.apply_boundary_values(bd, bv)
-        return dev.solve_time_step(nsx.YOSIDA)  # raises on non-convergence
+        def one_step(first):
+            nonlocal t
+            t += DT
+            if first:
+                dev.assemble(nsx.TEMAM)
+            else:
+                dev.assemble_time_step(0)
+            bd, bv = cylinder_boundary_values(dofs, inlet, t)
+            dev.apply_boundary_values(bd, bv)
+            return dev.solve_time_step(nsx.YOSIDA)  # raises on non-convergence
 
-    one_step(True)  # the first step is the full assembly (reported separately by the reference)
-    for _ in range(warmup):
-        one_step(False)
-    if barrier:
-        barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        stats.append(one_step(False))
-    if barrier:
-        barrier()
-    elapsed = time.perf_counter() - t0
-    # per-kernel HIP-event pass (separate from the throughput pass: event pairs perturb the launch stream)
-    table = {}
-    if profile_steps:
-        dev.profile(True)
-        for _ in range(profile_steps):
+        one_step(True)  # the first step is the full assembly (reported separately by the reference, SURVEY 8d)
+        for _ in range(warmup):
             one_step(False)
-        table = dev.profile_table()
-        dev.profile(False)
-    dev.close()
-    return elapsed, stats, table
+        if barrier:
+            barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            stats.append(one_step(False))
+        if barrier:
+            barrier()
+        elapsed = time.perf_counter() - t0
+        state = (dev.gather_solution() if world > 1 else dev.solution_owned, t) if want_state else None
+        # per-kernel HIP-event pass (separate from the throughput pass: event pairs perturb the launch stream)
+        table, prof_stats = {}, []
+        if profile_steps:
+            dev.profile(True)
+            for _ in range(profile_steps):
+                prof_stats.append(one_step(False))
+            table = dev.profile_table()
+            dev.profile(False)
+        return elapsed, stats, table, prof_stats, state
+    finally:
+        dev.close()
 
 
-def cpu_baseline(level=2, ranks=16):
-    """Oracle (CPU restatement of the reference algorithm, 1 core) on a bounded sample of the same workload."""
-    import numpy as np
+def cpu_step_from_state(dofs, tables, x, t_state, threads):
+    """One time step (assemble_time_step + Dirichlet values + Yosida solve_time_step) of the oracle from the velocity /
+    pressure state `x` (numbering of `dofs`) at time t_state.  Untimed before it: orc_create and the first full assembly
+    (mass, stiffness, B blocks: NavierStokes::assemble), which the reference also runs once per run."""
     import oracle
     from navierstokes_project_nm4pde_amd.problem import InletVelocity, cylinder_boundary_values
-    mesh, dofs, tables = build_problem(level, ranks)
-    nu, dt = 1e-3, 2e-4
-    o = oracle.Oracle(dofs, tables, nu, dt)
+    t0 = time.perf_counter()
+    o = oracle.Oracle(dofs, tables, NU, DT, threads=threads)
+    t_create = time.perf_counter() - t0
     inlet = InletVelocity(3)
-    o.assemble(oracle.TEMAM)
-    bd, bv = cylinder_boundary_values(dofs, inlet, dt)
-    o.apply_boundary_values(bd, bv)
-    o.solve_time_step(oracle.YOSIDA)
+    t0 = time.perf_counter()
+    o.assemble(oracle.TEMAM)  # from u = 0: convection matrix = 0, exactly what assemble_time_step expects to subtract
+    t_first = time.perf_counter() - t0
+    o.solution[:] = x
+    o.solution_owned[:] = x
     t0 = time.perf_counter()
     o.assemble_time_step(0)
-    bd, bv = cylinder_boundary_values(dofs, inlet, 2 * dt)
+    bd, bv = cylinder_boundary_values(dofs, inlet, t_state + DT)
     o.apply_boundary_values(bd, bv)
+    t_asm = time.perf_counter() - t0
     st = o.solve_time_step(oracle.YOSIDA)
     el = time.perf_counter() - t0
-    return dofs, tables, {"value": 1.0 / el, "unit": "time-steps/s", "cores": 1, "kind": "port",
-                          "sample": "1 time step (assemble_time_step + Dirichlet + Yosida solve_time_step) of the same 3D cylinder "
-                                    "problem on a %d-DoF mesh (level %d, %d ranks), oracle/nsx_oracle.c, gcc -O3, %d outer its"
-                                    % (dofs.n_dofs, level, ranks, st["outer_iterations"]),
-                          "sample_dofs": dofs.n_dofs, "sample_seconds": el}
+    if st["status"]:
+        raise RuntimeError("cpu_baseline: the oracle's solve did not converge (status %d)" % st["status"])
+    return {"seconds": el, "threads": o.threads, "outer": st["outer_iterations"], "inner_F": st["inner_F_iterations"],
+            "inner_S": st["inner_S_iterations"], "t_assemble": t_asm, "t_prec": st["t_prec"], "t_solve": st["t_solve"],
+            "untimed_create_s": t_create, "untimed_first_assembly_s": t_first}
+
+
+def cpu_baseline(gpu_dofs, gpu_state, device, small_level=3):
+    """The stated CPU baseline, timed on this box's host cores in this run:
+    (i) ALL usable cores on the bench workload itself (same mesh, same state, R = cores ranks as `mpirun -n cores` of
+        the reference would have, first-touch numbering): oracle/liboracle_mt.so, the oracle's source built with OpenMP;
+    (ii) ONE core, the serial reference-shaped restatement (oracle/liboracle.so, R = 1) on the largest mesh that
+        finishes in about a minute, with the GPU on that same small problem beside it."""
+    import oracle
+    cores = oracle.usable_cores()
+    x, t_state = gpu_state
+    # (i) all cores, full workload
+    mesh, dofs, tables = build_problem(BASE_LEVEL, cores, 1, "first_touch")
+    r = cpu_step_from_state(dofs, tables, transfer_state(gpu_dofs, x, dofs), t_state, cores)
+    out = {"value": 1.0 / r["seconds"], "unit": "time-steps/s", "cores": r["threads"], "kind": "port",
+           "sample": "1 time step (assemble_time_step + Dirichlet + Yosida solve_time_step) of the bench workload itself: the %d-DoF mesh, "
+                     "started from the GPU run's state at t = %.4f, %d MPI-rank ILU blocks (first-touch numbering, as `mpirun -n %d`), "
+                     "oracle/nsx_oracle.c built with -fopenmp -O3 on %d threads; %d outer / %d inner-F / %d inner-S iterations"
+                     % (dofs.n_dofs, t_state, cores, cores, r["threads"], r["outer"], r["inner_F"], r["inner_S"]),
+           "sample_dofs": dofs.n_dofs, "sample_seconds": r["seconds"], "phases_s": {k: r[k] for k in ("t_assemble", "t_prec", "t_solve")},
+           "untimed_setup_s": {"orc_create": r["untimed_create_s"], "first_assembly": r["untimed_first_assembly_s"]}}
+    del mesh, dofs
+    # (ii) one core, reference-shaped, bounded sample.  A short GPU run on that small mesh provides the state to start from
+    # (64 virtual ranks there: the state depends on the layout only through the solver tolerance)
+    _, gd, gt = build_problem(small_level, 64, 1, "colour")
+    e2, _, _, _, s_state = gpu_run(gd, gt, 3, 1, 0, device, profile_steps=0, want_state=True)
+    _, sd, st = build_problem(small_level, 1, 1, "first_touch")
+    r1 = cpu_step_from_state(sd, st, transfer_state(gd, s_state[0], sd), s_state[1], 1)
+    out["one_core"] = {"value": 1.0 / r1["seconds"], "unit": "time-steps/s", "cores": 1, "kind": "port",
+                       "sample": "the same step on the %d-DoF mesh (level %d), 1 rank (the serial reference's layout), oracle/nsx_oracle.c "
+                                 "gcc -O3, %d outer / %d inner-F iterations" % (sd.n_dofs, small_level, r1["outer"], r1["inner_F"]),
+                       "sample_dofs": sd.n_dofs, "sample_seconds": r1["seconds"],
+                       "gpu_same_mesh_64_virtual_ranks_steps_per_s": 3 / e2}
+    return out
+
+
+def layout_table(device, out_path, steps=2):
+    """Outer / inner iteration counts of the Yosida-preconditioned solve at full size for the preconditioner layouts the
+    reference can produce: R MPI ranks (= ILU(0) blocks) x node order inside a rank.  R = 1 is the serial reference,
+    R = 8 one rank per GPU of the target node, R = 4096 the bench's virtual-rank layout.  Counts only (untimed kernels:
+    few large blocks run through the level-per-launch ILU path)."""
+    import numpy as np  # noqa: F401
+    rows = []
+    for ranks, schur in ((4096, 512), (8, 8), (1, 1)):
+        for ordering in ("colour", "first_touch"):
+            mesh, dofs, tables = build_problem(BASE_LEVEL, ranks, 1, ordering)
+            t0 = time.perf_counter()
+            n = steps if ranks > 1 or ordering == "colour" else 1  # R = 1 first-touch: ~7000 dependency levels per sweep
+            elapsed, stats, _, _, _ = gpu_run(dofs, tables, n, 1, schur, device, profile_steps=0)
+            row = {"ranks": ranks, "schur_blocks": schur, "ordering": ordering, "n_dofs": dofs.n_dofs, "steps": n,
+                   "outer_per_step": sum(s["outer_iterations"] for s in stats) / n,
+                   "inner_F_per_step": sum(s["inner_F_iterations"] for s in stats) / n,
+                   "inner_S_per_step": sum(s["inner_S_iterations"] for s in stats) / n,
+                   "ms_per_step": 1e3 * elapsed / n, "wall_s": time.perf_counter() - t0}
+            rows.append(row)
+            print("[layout] %s" % json.dumps(row), file=sys.stderr, flush=True)
+            del mesh, dofs
+    doc = {"what": "iteration counts per time step, 3D cylinder level 7 (1 089 643 DoF), Yosida, reference tolerances, after first step + 1 warm-up step",
+           "command": "python3 bench.py --layout-table %s" % out_path, "rows": rows}
+    with open(out_path, "w") as f:
+        json.dump(doc, f, indent=1)
+    return doc
+
+
+def committed_layouts():
+    try:
+        with open(os.path.join(ROOT, LAYOUT_PROFILE)) as f:
+            doc = json.load(f)
+        return {"source": LAYOUT_PROFILE + " (measured on MI355X by `bench.py --layout-table`, not in this run)",
+                "rows": [{k: r[k] for k in ("ranks", "schur_blocks", "ordering", "outer_per_step", "inner_F_per_step", "inner_S_per_step", "steps")}
+                         for r in doc["rows"]]}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def summarise_kernels(table, prof_stats):
+    n_prof = max(1, len(prof_stats))
+    kernels = {}
+    for k, v in table.items():
+        if v["launches"] == 0:
+            continue
+        avg_s = v["total_ms"] * 1e-3 / v["launches"]
+        kernels[k] = {"launches_per_step": v["launches"] / float(n_prof), "avg_us": avg_s * 1e6,
+                      "alg_GBps": (v["bytes_per_launch"] / avg_s / 1e9) if avg_s > 0 and v["bytes_per_launch"] > 0 else None,
+                      "share": v["total_ms"]}
+    tot = sum(v["share"] for v in kernels.values()) or 1.0
+    for v in kernels.values():
+        v["share"] = v["share"] / tot
+    return kernels, tot / n_prof
 
 
 def main():
@@ -144,134 +274,141 @@ def main():
                          "iterations; ten steps average over that)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--level", type=int, default=None, help="mesh level (default: 7 ~ 1.09M DoF per GPU)")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak", help="which figure becomes `value` for N > 1 (both are reported)")
     ap.add_argument("--ranks", type=int, default=4096, help="virtual MPI ranks = ILU(0) blocks of F")
     ap.add_argument("--schur-blocks", type=int, default=512, help="ILU(0) blocks of the Schur matrix")
     ap.add_argument("--ordering", choices=("colour", "first_touch"), default="colour",
                     help="velocity node order inside a virtual rank (include/nsx_host.h: nsxh_distribute_dofs_ordered)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-only", action="store_true", help="only the cpu_baseline leg (after a short GPU run that provides its state)")
+    ap.add_argument("--layout-table", metavar="FILE", help="write the preconditioner-layout iteration table to FILE and exit")
+    ap.add_argument("--profile-steps", type=int, default=5)
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: start one process per GPU as a CHILD (nothing here has touched the GPU yet) and relay its line
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", os.environ.get("MASTER_PORT", "29517"), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
+    if args.gpus > 1 and world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if "NSX_BENCH_DEVICE" in os.environ:  # development only: several ranks on one card
         local_rank = int(os.environ["NSX_BENCH_DEVICE"])
     import torch
-    barrier = None
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group(os.environ.get("NSX_BENCH_PG", "nccl"))  # "gloo" only for the one-card rehearsal
+        on_cpu = dist.get_backend() == "gloo"
+
         def barrier():
             dist.barrier()
             torch.cuda.synchronize()
+
+        def max_over_ranks(v):
+            tt = torch.tensor([v], dtype=torch.float64, device="cpu" if on_cpu else "cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item())
     else:
         def barrier():
             torch.cuda.synchronize()
 
-    mode = "partitioned"
-    base_level = 7
-    if args.level is None:
-        args.level = base_level if (world == 1 or args.scaling == "strong") else {2: 9, 4: 11, 8: 14}.get(world, int(round(7 * world ** (1 / 3.0))))
-    base_ranks, base_schur = args.ranks, args.schur_blocks
-    if world > 1 and args.scaling == "weak":  # same rows per virtual rank on every GPU
-        args.ranks *= world
-        args.schur_blocks *= world
-    mesh, dofs, tables = build_problem(args.level, args.ranks, world, args.ordering)
-    # profiling pass on all ranks (collective calls inside the solve must match on every rank)
-    try:
-        elapsed, stats, table = gpu_run(dofs, tables, args.steps, args.warmup, args.schur_blocks, local_rank,
-                                        profile_steps=2, barrier=barrier, rank=rank, world=world)
-        failed = ""
-    except Exception as e:  # noqa: BLE001 - reported in the JSON line below
-        if world == 1:
-            raise
-        failed = "%s: %s" % (type(e).__name__, e)
-    if world > 1:
-        # did every rank get through the partitioned run?  (torch's own process group, independent of libnsx's communicator)
-        import torch.distributed as dist
-        flag = torch.tensor([0 if failed else 1], dtype=torch.int32, device="cpu" if dist.get_backend() == "gloo" else "cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            # last resort so that the scaling run still yields a line: N independent replicas of the whole problem (weak scaling)
-            mode = "replicas (partitioned run failed on a rank: %s)" % (failed or "another rank")
-            # every GPU advances its own copy of the N = 1 workload
-            args.level, args.ranks, args.schur_blocks = base_level, base_ranks, base_schur
-            mesh, dofs, tables = build_problem(args.level, args.ranks, 1, args.ordering)
-            elapsed, stats, table = gpu_run(dofs, tables, args.steps, args.warmup, args.schur_blocks, local_rank,
-                                            profile_steps=2 if rank == 0 else 0, barrier=barrier, rank=0, world=1)
-    if world > 1:
-        import torch.distributed as dist
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        def max_over_ranks(v):
+            return v
+
+    if args.layout_table:
+        layout_table(local_rank, args.layout_table)
+        return
+
+    def partitioned_run(level, ranks, schur, steps, warmup, profile_steps, want_state=False):
+        """every rank runs its part; a failure anywhere ends the job with a non-zero exit code (the launcher tears the
+        group down) — a GPU fault must be investigated, not converted into a throughput number"""
+        mesh, dofs, tables = build_problem(level, ranks, world, args.ordering)
+        try:
+            el, stats, table, prof_stats, state = gpu_run(dofs, tables, steps, warmup, schur, local_rank, profile_steps=profile_steps,
+                                                          barrier=barrier, rank=rank, world=world, want_state=want_state)
+        except Exception as e:  # noqa: BLE001
+            print("bench.py: rank %d failed in the partitioned run: %s: %s" % (rank, type(e).__name__, e), file=sys.stderr, flush=True)
+            os._exit(3)  # peers may be blocked inside a collective: leave at once and let the launcher end them
+        return max_over_ranks(el), stats, table, prof_stats, state, dofs
+
+    weak_level = args.level if args.level is not None else (BASE_LEVEL if world == 1 else {2: 9, 4: 11, 8: 14}.get(world, int(round(7 * world ** (1 / 3.0)))))
+    steps, warmup = (args.steps, args.warmup) if not args.cpu_only else (2, 1)
+    # ---- weak: ~1.09M DoF per GPU, virtual ranks and Schur blocks x N (same rows per ILU block on every GPU)
+    elapsed, stats, table, prof_stats, state, dofs = partitioned_run(weak_level, args.ranks * world, args.schur_blocks * world, steps, warmup,
+                                                                     0 if args.cpu_only else args.profile_steps, want_state=(world == 1 and not args.no_cpu))
+    raw = steps / elapsed
+    weak_value = raw * dofs.n_dofs / BASE_DOFS
+    strong = None
+    if world > 1 and args.level is None:
+        # ---- strong: the 1.09M-DoF mesh of the N = 1 line partitioned over the N GPUs
+        el_s, stats_s, _, _, _, dofs_s = partitioned_run(BASE_LEVEL, args.ranks, args.schur_blocks, steps, warmup, 0)
+        strong = {"time_steps_per_s_of_this_mesh": steps / el_s, "ms_per_step": 1e3 * el_s / steps, "n_dofs": dofs_s.n_dofs,
+                  "gmres_outer_iters_per_step": sum(s["outer_iterations"] for s in stats_s) / max(1, len(stats_s))}
     if rank != 0:
         if world > 1:
             torch.distributed.destroy_process_group()
         return
 
-    # partitioned: the whole job advances `steps` steps of ONE problem; replicas: every rank advances its own copy
-    raw_steps_per_s = args.steps / elapsed
-    base_dofs = 1089643  # level-7 mesh, the N = 1 workload
-    if mode != "partitioned":
-        steps_per_s = world * raw_steps_per_s
-    elif world > 1 and args.scaling == "weak":
-        steps_per_s = raw_steps_per_s * dofs.n_dofs / base_dofs
-    else:
-        steps_per_s = raw_steps_per_s
+    if args.cpu_only:
+        print(json.dumps(cpu_baseline(dofs, state, local_rank)))
+        return
+
     outer = sum(s["outer_iterations"] for s in stats)
     t_solve = sum(s["t_solve"] for s in stats)
+    kernels, kernel_ms_per_profiled_step = summarise_kernels(table, prof_stats)
     # roofline of the dominant kernel (by summed HIP-event time over the profiled steps)
-    kernels = {}
-    for k, v in table.items():
-        if v["launches"] == 0:
-            continue
-        avg_s = v["total_ms"] * 1e-3 / v["launches"]
-        kernels[k] = {"launches_per_step": v["launches"] / 2.0, "avg_us": avg_s * 1e6,
-                      "alg_GBps": (v["bytes_per_launch"] / avg_s / 1e9) if avg_s > 0 and v["bytes_per_launch"] > 0 else None,
-                      "share": v["total_ms"]}
-    tot = sum(v["share"] for v in kernels.values()) or 1.0
-    for v in kernels.values():
-        v["share"] = v["share"] / tot
     dom = max((k for k in kernels if kernels[k]["alg_GBps"]), key=lambda k: kernels[k]["share"]) if kernels else None
     roof = None
     if dom:
         a = kernels[dom]["alg_GBps"]
+        traffic, traffic_src = pmc_traffic(dom)
         roof = {"kernel": dom, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(dom), "algorithmic_bytes": table[dom]["bytes_per_launch"],
-                "avg_us": kernels[dom]["avg_us"], "share_of_kernel_time": kernels[dom]["share"]}
+                "traffic": traffic, "traffic_source": ("constant from the committed rocprofv3 --pmc profile %s, not measured in this run" % traffic_src)
+                if traffic_src else None,
+                "algorithmic_bytes": table[dom]["bytes_per_launch"], "avg_us": kernels[dom]["avg_us"], "share_of_kernel_time": kernels[dom]["share"]}
         if "spmv_F" in kernels and kernels["spmv_F"]["alg_GBps"]:
             roof["spmv_F_GBps"] = kernels["spmv_F"]["alg_GBps"]
             roof["spmv_F_frac"] = kernels["spmv_F"]["alg_GBps"] / HBM_PEAK_GBS
+    use_strong = world > 1 and args.scaling == "strong" and strong
+    n = max(1, len(stats))
     out = {
-        "metric": "time-steps/sec (assemble_time_step + solve_time_step), 3D flow past a cylinder, P2/P1, Yosida",
-        "value": steps_per_s, "unit": "time-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling if mode == "partitioned" else "weak", "vs_baseline": None,
-        "time_steps_per_s_of_this_mesh": raw_steps_per_s,
+        "metric": "time-steps/sec (assemble_time_step + solve_time_step), 3D flow past a cylinder, P2/P1, Yosida, ILU(0) per rank with "
+                  "%d virtual ranks per GPU, %s node order" % (args.ranks, args.ordering),
+        "value": strong["time_steps_per_s_of_this_mesh"] if use_strong else weak_value, "unit": "time-steps/s", "n_gpus": world,
+        "steps": steps, "warmup": warmup, "ms_per_step": strong["ms_per_step"] if use_strong else 1e3 * elapsed / steps,
+        "higher_is_better": True, "scaling": "strong" if use_strong else "weak", "vs_baseline": None,
+        "time_steps_per_s_of_this_mesh": raw,
         "dtype": "f64", "data": "synthetic (block-structured tetrahedral cylinder mesh, u0 = 0, reference inlet profile)",
         "config": {"workload": "3D flow-past-cylinder, P2/P1 (reference FE_SimplexP), %d DoF, %d cells, dt=2e-4, nu=1e-3, u_m=9, "
                                "GMRES(1e-4 abs)+Yosida(inner 1e-2), ILU(0) per rank with %d ranks (Schur: %d blocks), %s node order inside a rank"
-                               % (dofs.n_dofs, dofs.n_cells, args.ranks, args.schur_blocks, args.ordering),
+                               % (dofs.n_dofs, dofs.n_cells, args.ranks * world, args.schur_blocks * world, args.ordering),
                    "n_dofs": dofs.n_dofs, "n_cells": dofs.n_cells,
-                   "parallelism": "mesh partitioned over %d GPU(s): RCCL ghost exchange + dot-product all-reduce" % world
-                   if mode == "partitioned" else mode},
-        "gmres_outer_iters_per_step": outer / max(1, len(stats)),
+                   "parallelism": "mesh partitioned over %d GPU(s): RCCL ghost exchange + dot-product all-reduce" % world},
+        "gmres_outer_iters_per_step": outer / n,
         "gmres_outer_iters_per_sec": outer / t_solve if t_solve > 0 else None,
-        "inner_F_iters_per_step": sum(s["inner_F_iterations"] for s in stats) / max(1, len(stats)),
-        "inner_S_iters_per_step": sum(s["inner_S_iterations"] for s in stats) / max(1, len(stats)),
+        "inner_F_iters_per_step": sum(s["inner_F_iterations"] for s in stats) / n,
+        "inner_S_iters_per_step": sum(s["inner_S_iterations"] for s in stats) / n,
+        "t_prec_ms_per_step": 1e3 * sum(s["t_prec"] for s in stats) / n,
         "roofline": roof,
         "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kernels.items()},
+        "kernel_profile": {"steps": len(prof_stats), "outer_iters_per_step": sum(s["outer_iterations"] for s in prof_stats) / max(1, len(prof_stats)),
+                           "kernel_ms_per_step": kernel_ms_per_profiled_step,
+                           "note": "per-kernel HIP-event pass over separate steps (not the timed ones); compare kernel_ms_per_step with "
+                                   "ms_per_step x outer_iters_per_step / gmres_outer_iters_per_step"},
     }
+    if strong:
+        out["strong"] = strong
+        out["weak"] = {"value": weak_value, "time_steps_per_s_of_this_mesh": raw, "n_dofs": dofs.n_dofs}
+    layouts = committed_layouts()
+    if layouts:
+        out["preconditioner_layouts"] = layouts
     if world == 1 and not args.no_cpu:
-        import multiprocessing
-        sd, st, cb = cpu_baseline()
-        # the same sample on the GPU, for a like-for-like ratio
-        e2, _, _ = gpu_run(sd, st, 3, 1, 0, local_rank, profile_steps=0)
-        cb["gpu_same_sample_steps_per_s"] = 3 / e2
-        cb["host_cores_available"] = multiprocessing.cpu_count()
-        cb["estimate_full_workload_steps_per_s"] = cb["value"] * cb["sample_dofs"] / dofs.n_dofs
-        out["cpu_baseline"] = cb
+        out["cpu_baseline"] = cpu_baseline(dofs, state, local_rank)
+        out["gpu_over_cpu_all_cores"] = out["value"] / out["cpu_baseline"]["value"]
     print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -120,6 +120,13 @@ struct IluSchedule {
   DevBuf<int64_t> dn_off;       // [n_blocks+1] offsets of the blocks' matrices in dn_P
   DevBuf<double> dn_P;
   int64_t dn_entries = 0;
+  // levelled path for blocks too large for one wave / one workgroup (few real MPI ranks: R = 1 is the serial reference,
+  // R = 8 one rank per GPU): the dependency levels of ALL blocks merged (blocks are independent, so level l of the
+  // schedule is the union of the blocks' level-l rows), one launch per level over all its rows.  in_lo/in_hi: CSR
+  // positions bounding the in-block entries of every row (columns are sorted, so they are one contiguous range).
+  bool levelled = false;
+  std::vector<int32_t> gl_f_ptr_h, gl_b_ptr_h;  // [levels+1] offsets into gl_f_rows / gl_b_rows
+  DevBuf<int32_t> gl_f_rows, gl_b_rows, in_lo, in_hi;
 };
 
 // Ghost exchange plan of one scalar space (the Epetra_Import of every vmult): neighbours in ascending rank order,

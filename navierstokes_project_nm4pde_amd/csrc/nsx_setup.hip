@@ -118,6 +118,41 @@ void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> 
       s.max_levels = std::max(s.max_levels, nl);
     }
   }
+  // ---- blocks beyond what one wave (packed stream) or one workgroup can hold: merged level lists, one launch per level
+  const int levelled_min = getenv("NSX_LEVELLED_MIN") ? atoi(getenv("NSX_LEVELLED_MIN")) : 4096;
+  s.levelled = s.max_rows > levelled_min;
+  s.packed_ok = false;
+  s.dense = false;
+  if (s.levelled) {
+    for (int pass = 0; pass < 2; ++pass) {
+      const auto &ptr = pass == 0 ? f_ptr : b_ptr;
+      const auto &rows = pass == 0 ? f_rows : b_rows;
+      const auto &off = pass == 0 ? off_f : off_b;
+      std::vector<int32_t> gptr(s.max_levels + 1, 0), grows(rows.size());
+      for (int b = 0; b < nb; ++b)
+        for (int l = off[b]; l < off[b + 1]; ++l) gptr[l - off[b] + 1] += ptr[l + 1] - ptr[l];
+      for (int l = 0; l < s.max_levels; ++l) gptr[l + 1] += gptr[l];
+      std::vector<int32_t> fill(gptr.begin(), gptr.end() - 1);
+      for (int b = 0; b < nb; ++b)
+        for (int l = off[b]; l < off[b + 1]; ++l)
+          for (int q = ptr[l]; q < ptr[l + 1]; ++q) grows[fill[l - off[b]]++] = rows[q];
+      (pass == 0 ? s.gl_f_ptr_h : s.gl_b_ptr_h) = gptr;
+      (pass == 0 ? s.gl_f_rows : s.gl_b_rows).upload(grows, h->stream);
+    }
+    std::vector<int32_t> lo(g.n_rows), hi(g.n_rows);
+    for (int b = 0; b < nb; ++b)
+      for (int i = bptr[b]; i < bptr[b + 1]; ++i) {
+        const int32_t *cb = g.colind.data() + g.rowptr[i], *ce = g.colind.data() + g.rowptr[i + 1];
+        lo[i] = (int32_t)(std::lower_bound(cb, ce, bptr[b]) - g.colind.data());
+        hi[i] = (int32_t)(std::lower_bound(cb, ce, bptr[b + 1]) - g.colind.data());
+      }
+    s.in_lo.upload(lo, h->stream);
+    s.in_hi.upload(hi, h->stream);
+    s.block_ptr.upload(bptr, h->stream);
+    if (getenv("NSX_DEBUG"))
+      fprintf(stderr, "[nsx] ilu schedule: rows %d blocks %d max_rows %d -> levelled, %d levels\n", g.n_rows, nb, s.max_rows, s.max_levels);
+    return;
+  }
   s.block_ptr.upload(bptr, h->stream);
   s.fwd_lvl_ptr.upload(f_ptr, h->stream);
   s.fwd_rows.upload(f_rows, h->stream);

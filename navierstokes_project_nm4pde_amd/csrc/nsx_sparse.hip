@@ -586,13 +586,119 @@ __global__ __launch_bounds__(ILU_WAVES * 64) void k_ilu_factor_small(const int32
   }
 }
 
+// ---- levelled path (IluSchedule::levelled): blocks of any size, one launch per dependency level ------------------------
+// Factorisation: one wave per row of the level, same row arithmetic as k_ilu_factor (sorted-column binary search in global
+// memory); rows of earlier levels are complete because the previous launch has finished.
+__global__ __launch_bounds__(ILU_WAVES * 64) void k_ilu_factor_level(int n_lvl_rows, const int32_t *__restrict__ rows,
+                                                                    const int32_t *__restrict__ in_lo, const int32_t *__restrict__ in_hi,
+                                                                    const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                                    const int32_t *__restrict__ diag, const double *__restrict__ a,
+                                                                    double *lu, int *__restrict__ err) {
+  __shared__ double wv[ILU_WAVES][ILU_MAXROW];
+  const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+  const int r = blockIdx.x * ILU_WAVES + wave;
+  if (r >= n_lvl_rows) return;  // whole waves exit; no workgroup barrier below
+  const int i = rows[r];
+  volatile double *w = wv[wave];
+  const int p0 = rp[i], n = rp[i + 1] - p0, dpos = diag[i] - p0, lo = in_lo[i] - p0, hi = in_hi[i] - p0;
+  if (n > ILU_MAXROW) {
+    if (lane == 0) *err = 1;
+    return;
+  }
+  for (int t = lane; t < n; t += 64) w[t] = (t >= lo && t < hi) ? a[p0 + t] : 0.0;
+  __builtin_amdgcn_wave_barrier();
+  for (int t = lo; t < dpos; ++t) {  // L part, ascending columns (wave-uniform loop)
+    const int j = ci[p0 + t];
+    const int dj = diag[j];
+    const double mult = w[t];
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) w[t] = mult * lu[dj];  // InV[jj] *= DV[j]
+    const int ue = in_hi[j];
+    for (int q = dj + 1 + lane; q < ue; q += 64) {  // scaled U row of j
+      const int c = ci[q];
+      int l2 = t + 1, h2 = hi - 1;  // columns of row i are sorted; c > j
+      while (l2 <= h2) {
+        const int mid = (l2 + h2) >> 1, cm = ci[p0 + mid];
+        if (cm < c) l2 = mid + 1; else if (cm > c) h2 = mid - 1; else { w[mid] -= mult * lu[q]; break; }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  const double d = w[dpos];
+  const double dinv = 1.0 / d;
+  if (lane == 0 && !(fabs(d) > 0.0)) *err = 2;
+  for (int t = lane; t < n; t += 64) {
+    double v = w[t];
+    if (t == dpos) v = dinv;
+    else if (t > dpos) v = t < hi ? v * dinv : 0.0;
+    lu[p0 + t] = v;
+  }
+}
+
+// Solve: LW lanes per row of the level, x in global memory (in place: x holds b on entry of the forward sweep).
+// forward:  x_i -= sum_{j<i in block} L_ij x_j ;  backward: x_i = x_i / d_i - sum_{j>i in block} (U_ij/d_i) x_j
+// (the D^-1 scaling of Ifpack's ApplyInverse is folded into the backward visit of each row: its x_j are final by then)
+template <int NCOMP, int LW, bool FWD>
+__global__ __launch_bounds__(256) void k_ilu_solve_level(int n_lvl_rows, const int32_t *__restrict__ rows, const int32_t *__restrict__ in_lo,
+                                                         const int32_t *__restrict__ in_hi, const int32_t *__restrict__ ci,
+                                                         const int32_t *__restrict__ diag, const double *__restrict__ lu, double *x) {
+  const int r = (blockIdx.x * 256 + threadIdx.x) / LW, lane = threadIdx.x % LW;
+  if (r >= n_lvl_rows) return;
+  const int i = rows[r];
+  const int d = diag[i];
+  const int pb = FWD ? in_lo[i] : d + 1, pe = FWD ? d : in_hi[i];
+  double acc[NCOMP];
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c) acc[c] = 0.0;
+  for (int p = pb + lane; p < pe; p += LW) {
+    const double l = lu[p];
+    const double *xj = x + (size_t)ci[p] * NCOMP;
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) acc[c] += l * xj[c];
+  }
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c) acc[c] = lane_group_sum<LW>(acc[c]);
+  if (lane == 0) {
+    double *xi = x + (size_t)i * NCOMP;
+    const double dinv = FWD ? 1.0 : lu[d];
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) xi[c] = FWD ? xi[c] - acc[c] : xi[c] * dinv - acc[c];
+  }
+}
+
+template <int NCOMP>
+static void ilu_solve_levelled(nsx_handle *h, const DevCsr &g, const IluSchedule &s, const double *lu, const double *b, double *x) {
+  constexpr int LW = 8;
+  v_copy(h, g.n_rows() * NCOMP, x, b);
+  const int nf = (int)s.gl_f_ptr_h.size() - 1, nbk = (int)s.gl_b_ptr_h.size() - 1;
+  for (int l = 1; l < nf; ++l) {  // level 0 of the forward sweep has no in-block L entries: y = b there
+    const int n = s.gl_f_ptr_h[l + 1] - s.gl_f_ptr_h[l];
+    if (n > 0)
+      hipLaunchKernelGGL((k_ilu_solve_level<NCOMP, LW, true>), dim3(cdiv((int64_t)n * LW, 256)), dim3(256), 0, h->stream, n,
+                         s.gl_f_rows.p + s.gl_f_ptr_h[l], s.in_lo.p, s.in_hi.p, g.colind.p, g.diag.p, lu, x);
+  }
+  for (int l = 0; l < nbk; ++l) {
+    const int n = s.gl_b_ptr_h[l + 1] - s.gl_b_ptr_h[l];
+    if (n > 0)
+      hipLaunchKernelGGL((k_ilu_solve_level<NCOMP, LW, false>), dim3(cdiv((int64_t)n * LW, 256)), dim3(256), 0, h->stream, n,
+                         s.gl_b_rows.p + s.gl_b_ptr_h[l], s.in_lo.p, s.in_hi.p, g.colind.p, g.diag.p, lu, x);
+  }
+}
+
 void ilu_factor(nsx_handle *h, const DevCsr &g, IluSchedule &s, const double *vals, double *lu, const char *name) {
   int *err = (int *)(h->scal.p + (N_SLOTS - 1));
   HIP_CHECK(hipMemsetAsync(err, 0, sizeof(double), h->stream));
   {
     LaunchScope ls(h, name, 20.0 * g.nnz() + 12.0 * g.n_rows());
     static const bool small_ok = !(getenv("NSX_ILU_SMALL") && atoi(getenv("NSX_ILU_SMALL")) == 0);
-    if (small_ok && s.max_rows <= ILU_DENSE_ROWS)
+    if (s.levelled) {
+      for (size_t l = 0; l + 1 < s.gl_f_ptr_h.size(); ++l) {
+        const int n = s.gl_f_ptr_h[l + 1] - s.gl_f_ptr_h[l];
+        if (n > 0)
+          hipLaunchKernelGGL(k_ilu_factor_level, dim3(cdiv(n, ILU_WAVES)), dim3(ILU_WAVES * 64), 0, h->stream, n, s.gl_f_rows.p + s.gl_f_ptr_h[l],
+                             s.in_lo.p, s.in_hi.p, g.rowptr.p, g.colind.p, g.diag.p, vals, lu, err);
+      }
+    } else if (small_ok && s.max_rows <= ILU_DENSE_ROWS)
       hipLaunchKernelGGL(k_ilu_factor_small, dim3(s.n_blocks), dim3(ILU_WAVES * 64), 0, h->stream, s.block_ptr.p, s.blk_lvl_off.p,
                          s.fwd_lvl_ptr.p, s.fwd_rows.p, g.rowptr.p, g.colind.p, g.diag.p, vals, lu, s.packed_ok ? s.pk_slot_of.p : nullptr,
                          s.pk_val.p, s.pk_dinv.p, err);
@@ -881,6 +987,13 @@ static void launch_ilu_solve(nsx_handle *h, const DevCsr &g, const IluSchedule &
 
 bool ilu_solve(nsx_handle *h, const DevCsr &g, const IluSchedule &s, const double *lu, const double *b, double *x, int ncomp,
                const char *name, int dot_slot) {
+  if (s.levelled) {
+    LaunchScope ls(h, name, 12.0 * g.nnz() + (double)g.n_rows() * (4 + 16.0 * ncomp));
+    if (ncomp == 1) ilu_solve_levelled<1>(h, g, s, lu, b, x);
+    else if (ncomp == 2) ilu_solve_levelled<2>(h, g, s, lu, b, x);
+    else ilu_solve_levelled<3>(h, g, s, lu, b, x);
+    return false;
+  }
   const bool packed = s.packed_ok && (size_t)s.max_wave_rows * ncomp * sizeof(double) <= 64 * 1024;
   if (s.dense && ncomp == 1 && (size_t)s.max_rows * sizeof(double) <= 48 * 1024) {
     LaunchScope ls(h, name, 8.0 * (double)s.dn_entries + 16.0 * g.n_rows());

@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(_HERE, "liboracle.so")
+SO = os.path.join(_HERE, "liboracle.so")        # serial, reference-shaped: what the parity tests check against
+SO_MT = os.path.join(_HERE, "liboracle_mt.so")  # same source with -fopenmp: bench.py's all-host-cores CPU baseline
 
 _i32p = C.POINTER(C.c_int32)
 _f64p = C.POINTER(C.c_double)
@@ -27,15 +28,31 @@ class Stats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(SO):
-            raise OSError("%s missing: run `make oracle`" % SO)
-        L = C.CDLL(SO)
+def usable_cores():
+    """CPU cores this process may actually use: scheduler affinity capped by the cgroup CPU quota (a GPU box hands a
+    one-GPU job a share of its host cores, not all of them)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def lib(mt=False):
+    so = SO_MT if mt else SO
+    if so not in _libs:
+        if not os.path.exists(so):
+            raise OSError("%s missing: run `make oracle`" % so)
+        L = C.CDLL(so)
+        L.orc_threads.restype = C.c_int
+        L.orc_set_threads.argtypes = [C.c_int]
         vp = C.c_void_p
         L.orc_create.restype = vp
         L.orc_create.argtypes = [C.c_int] * 5 + [_i32p, _f64p] + [C.c_int] * 3 + [_f64p] * 4 + \
@@ -66,8 +83,8 @@ def lib():
         L.orc_ilu0_solve.argtypes = [C.c_int, _i32p, _i32p, _f64p, C.c_int, _i32p, _f64p, _f64p]
         L.orc_prec_initialize.argtypes = [vp, C.c_int]
         L.orc_prec_vmult.argtypes = [vp, C.c_int, C.c_double, C.c_int, _f64p, _f64p, C.POINTER(Stats)]
-        _lib = L
-    return _lib
+        _libs[so] = L
+    return _libs[so]
 
 
 def _i(a):
@@ -89,8 +106,13 @@ def _cd(a):
 class Oracle:
     """One `NavierStokes` problem instance of the restated reference algorithm (raw arrays in, raw arrays out)."""
 
-    def __init__(self, dofs, tables, nu, deltat):
-        L = lib()
+    def __init__(self, dofs, tables, nu, deltat, threads=1):
+        """threads = 1: the serial restatement (liboracle.so).  threads > 1: the OpenMP build of the same source
+        (liboracle_mt.so) on that many threads — only bench.py's cpu_baseline leg uses it."""
+        L = lib(mt=threads > 1)
+        if threads > 1:
+            L.orc_set_threads(int(threads))
+        self.threads = L.orc_threads()
         self.L = L
         self.dim, self.n_u, self.n_p = dofs.dim, dofs.n_u, dofs.n_p
         self.n = self.n_u + self.n_p

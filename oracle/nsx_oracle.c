@@ -6,9 +6,20 @@
  * Gram-Schmidt + Kelley re-orthogonalisation, SolverCG, MatrixTools::apply_boundary_values for Trilinos block
  * matrices) and Ifpack (Ifpack_ILU level 0, overlap 0); those restatements are marked [lib].
  */
+/* Threads: the same file builds twice.  liboracle.so (no -fopenmp: every `#pragma omp` below is ignored) is the serial,
+ * reference-shaped restatement the parity tests check against.  liboracle_mt.so (-fopenmp) is the "all host cores"
+ * CPU baseline of bench.py: the loops the reference distributes over MPI ranks run on OpenMP threads instead
+ * (cells of the assembly loop, rows of every vmult / mmult, the per-rank ILU(0) blocks, Epetra's BLAS-1 with its
+ * MPI_Allreduce as an OpenMP reduction).  Same algorithm and data layout; only the summation order of the
+ * reductions and of the concurrent `add`s differs (as it does between two MPI runs). */
+#define _DEFAULT_SOURCE
 #define _POSIX_C_SOURCE 200809L
 #include "nsx_oracle.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
+#include <malloc.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -45,6 +56,22 @@ struct orc {
   double alpha_simple, alpha_asimple;
 };
 
+/* threads the library was built for and will use (1 = the serial restatement) */
+int orc_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+void orc_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 static double now_s(void) {
   struct timespec ts;
   clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -75,6 +102,7 @@ static void *dup_mem(const void *src, size_t bytes) {
 /* ------------------------------------------------------------------ BLAS-1 (Epetra_Vector ops) */
 static double v_dot(int n, const double *a, const double *b) {
   double s = 0;
+#pragma omp parallel for reduction(+ : s) schedule(static)
   for (int i = 0; i < n; ++i) s += a[i] * b[i];
   return s;
 }
@@ -82,19 +110,24 @@ static double v_norm(int n, const double *a) { return sqrt(v_dot(n, a, a)); }
 static void v_copy(int n, double *d, const double *s) { memcpy(d, s, (size_t)n * sizeof(double)); }
 static void v_zero(int n, double *d) { memset(d, 0, (size_t)n * sizeof(double)); }
 static void v_add(int n, double *d, double a, const double *v) { /* d += a v */
+#pragma omp parallel for schedule(static)
   for (int i = 0; i < n; ++i) d[i] += a * v[i];
 }
 static void v_sadd(int n, double *d, double s, double a, const double *v) { /* d = s d + a v */
+#pragma omp parallel for schedule(static)
   for (int i = 0; i < n; ++i) d[i] = s * d[i] + a * v[i];
 }
 static void v_scale(int n, double *d, double a) {
+#pragma omp parallel for schedule(static)
   for (int i = 0; i < n; ++i) d[i] *= a;
 }
 static void v_scale_vec(int n, double *d, const double *f) { /* Vector::scale(factors) */
+#pragma omp parallel for schedule(static)
   for (int i = 0; i < n; ++i) d[i] *= f[i];
 }
 static double v_add_and_dot(int n, double *d, double a, const double *v, const double *w) { /* d += a v; return d.w */
   double s = 0;
+#pragma omp parallel for reduction(+ : s) schedule(static)
   for (int i = 0; i < n; ++i) {
     d[i] += a * v[i];
     s += d[i] * w[i];
@@ -109,6 +142,7 @@ static int v_all_zero(int n, const double *d) {
 
 /* ------------------------------------------------------------------ sparse kernels */
 void orc_spmv(int n_rows, const int32_t *rp, const int32_t *ci, const double *v, const double *x, double *y) {
+#pragma omp parallel for schedule(static)
   for (int i = 0; i < n_rows; ++i) { /* Epetra_CrsMatrix::Multiply [lib] */
     double s = 0;
     for (int k = rp[i]; k < rp[i + 1]; ++k) s += v[k] * x[ci[k]];
@@ -144,52 +178,84 @@ static void mmult(csr_t *C, int a_rows, const int32_t *arp, const int32_t *aci, 
   C->n_rows = a_rows;
   C->n_cols = b_cols;
   C->rp = xcalloc((size_t)a_rows + 1, sizeof(int32_t));
-  int *mark = xmalloc((size_t)b_cols * sizeof(int));
-  double *acc = xcalloc((size_t)b_cols, sizeof(double));
-  for (int j = 0; j < b_cols; ++j) mark[j] = -1;
-  size_t cap = 1024, nnz = 0;
-  C->ci = xmalloc(cap * sizeof(int32_t));
-  C->v = xmalloc(cap * sizeof(double));
-  int *cols = xmalloc((size_t)b_cols * sizeof(int));
-  for (int i = 0; i < a_rows; ++i) {
-    int cnt = 0;
-    for (int ka = arp[i]; ka < arp[i + 1]; ++ka) {
-      const int k = aci[ka];
-      const double aik = av[ka] * V[k];
-      for (int kb = brp[k]; kb < brp[k + 1]; ++kb) {
-        const int j = bci[kb];
-        if (mark[j] != i) {
-          mark[j] = i;
-          acc[j] = 0;
-          cols[cnt++] = j;
+  /* rows are independent: each thread builds a contiguous chunk of rows in buffers of its own (the serial build is the
+   * one-chunk case), then the chunks are concatenated */
+  int n_chunks = 1;
+#ifdef _OPENMP
+  n_chunks = omp_get_max_threads();
+#endif
+  if (n_chunks > a_rows) n_chunks = a_rows > 0 ? a_rows : 1;
+  int32_t **cci = xcalloc((size_t)n_chunks, sizeof(*cci));
+  double **ccv = xcalloc((size_t)n_chunks, sizeof(*ccv));
+  size_t *cnnz = xcalloc((size_t)n_chunks, sizeof(*cnnz));
+#pragma omp parallel for schedule(static, 1)
+  for (int t = 0; t < n_chunks; ++t) {
+    const int i0 = (int)((long long)a_rows * t / n_chunks), i1 = (int)((long long)a_rows * (t + 1) / n_chunks);
+    int *mark = xmalloc((size_t)b_cols * sizeof(int));
+    double *acc = xcalloc((size_t)b_cols, sizeof(double));
+    int *cols = xmalloc((size_t)b_cols * sizeof(int));
+    for (int j = 0; j < b_cols; ++j) mark[j] = -1;
+    size_t cap = 1024, nnz = 0;
+    int32_t *oci = xmalloc(cap * sizeof(int32_t));
+    double *ov = xmalloc(cap * sizeof(double));
+    for (int i = i0; i < i1; ++i) {
+      int cnt = 0;
+      for (int ka = arp[i]; ka < arp[i + 1]; ++ka) {
+        const int k = aci[ka];
+        const double aik = av[ka] * V[k];
+        for (int kb = brp[k]; kb < brp[k + 1]; ++kb) {
+          const int j = bci[kb];
+          if (mark[j] != i) {
+            mark[j] = i;
+            acc[j] = 0;
+            cols[cnt++] = j;
+          }
+          acc[j] += aik * bv[kb];
         }
-        acc[j] += aik * bv[kb];
       }
-    }
-    /* sort the row's columns (insertion sort on small rows, qsort-free) */
-    for (int a = 1; a < cnt; ++a) {
-      int c = cols[a], b = a - 1;
-      while (b >= 0 && cols[b] > c) {
-        cols[b + 1] = cols[b];
-        --b;
+      /* sort the row's columns (insertion sort on small rows, qsort-free) */
+      for (int a = 1; a < cnt; ++a) {
+        int c = cols[a], b = a - 1;
+        while (b >= 0 && cols[b] > c) {
+          cols[b + 1] = cols[b];
+          --b;
+        }
+        cols[b + 1] = c;
       }
-      cols[b + 1] = c;
+      if (nnz + (size_t)cnt > cap) {
+        while (nnz + (size_t)cnt > cap) cap *= 2;
+        oci = realloc(oci, cap * sizeof(int32_t));
+        ov = realloc(ov, cap * sizeof(double));
+        if (!oci || !ov) abort();
+      }
+      for (int a = 0; a < cnt; ++a) {
+        oci[nnz] = cols[a];
+        ov[nnz++] = acc[cols[a]];
+      }
+      C->rp[i + 1] = (int32_t)cnt; /* row length for now */
     }
-    if (nnz + (size_t)cnt > cap) {
-      while (nnz + (size_t)cnt > cap) cap *= 2;
-      C->ci = realloc(C->ci, cap * sizeof(int32_t));
-      C->v = realloc(C->v, cap * sizeof(double));
-      if (!C->ci || !C->v) abort();
-    }
-    for (int a = 0; a < cnt; ++a) {
-      C->ci[nnz] = cols[a];
-      C->v[nnz++] = acc[cols[a]];
-    }
-    C->rp[i + 1] = (int32_t)nnz;
+    free(mark);
+    free(acc);
+    free(cols);
+    cci[t] = oci;
+    ccv[t] = ov;
+    cnnz[t] = nnz;
   }
-  free(mark);
-  free(acc);
-  free(cols);
+  for (int i = 0; i < a_rows; ++i) C->rp[i + 1] += C->rp[i];
+  const size_t total = (size_t)C->rp[a_rows];
+  C->ci = xmalloc(total * sizeof(int32_t));
+  C->v = xmalloc(total * sizeof(double));
+  size_t off = 0;
+  for (int t = 0; t < n_chunks; ++t) {
+    memcpy(C->ci + off, cci[t], cnnz[t] * sizeof(int32_t));
+    memcpy(C->v + off, ccv[t], cnnz[t] * sizeof(double));
+    off += cnnz[t];
+    free(cci[t]);
+    free(ccv[t]);
+  }
+  free(cci);
+  free(ccv);
+  free(cnnz);
 }
 
 /* Ifpack_ILU::Compute, level 0, relax 0, athresh 0, rthresh 1, overlap 0 [lib] — what
@@ -199,57 +265,66 @@ static void mmult(csr_t *C, int a_rows, const int32_t *arp, const int32_t *aci, 
  * strict upper = U row scaled by 1/d (unit upper). */
 void orc_ilu0_factor(int n_rows, const int32_t *rp, const int32_t *ci, const double *vals, int n_blocks,
                      const int32_t *bptr, double *out) {
-  int *colflag = xmalloc((size_t)n_rows * sizeof(int));
-  for (int i = 0; i < n_rows; ++i) colflag[i] = -1;
   memset(out, 0, (size_t)rp[n_rows] * sizeof(double));
-  for (int b = 0; b < n_blocks; ++b) {
-    const int r0 = bptr[b], r1 = bptr[b + 1];
-    for (int i = r0; i < r1; ++i) {
-      int diag = -1;
-      for (int k = rp[i]; k < rp[i + 1]; ++k) {
-        const int j = ci[k];
-        if (j < r0 || j >= r1) continue;
-        out[k] = vals[k];
-        colflag[j] = k;
-        if (j == i) diag = k;
-      }
-      if (diag < 0) {
-        fprintf(stderr, "nsx_oracle: ILU row %d has no diagonal entry\n", i);
-        abort();
-      }
-      for (int kk = rp[i]; kk < rp[i + 1]; ++kk) {
-        const int j = ci[kk];
-        if (j < r0 || j >= i) continue; /* L part, ascending columns */
-        const double multiplier = out[kk];
-        /* find diagonal of row j */
-        const int dj = row_find(rp, ci, j, j);
-        out[kk] *= out[dj]; /* InV[jj] *= DV[j] */
-        for (int ku = dj + 1; ku < rp[j + 1]; ++ku) { /* U row of j (already scaled) */
-          const int c = ci[ku];
-          if (c >= r1) break;
-          const int pos = colflag[c];
-          if (pos >= 0) out[pos] -= multiplier * out[ku];
+  /* the blocks (MPI ranks) are independent; colflag is indexed by block-local column so every thread owns a small one */
+  int max_rows = 0;
+  for (int b = 0; b < n_blocks; ++b)
+    if (bptr[b + 1] - bptr[b] > max_rows) max_rows = bptr[b + 1] - bptr[b];
+#pragma omp parallel
+  {
+    int *colflag = xmalloc((size_t)(max_rows ? max_rows : 1) * sizeof(int));
+    for (int i = 0; i < max_rows; ++i) colflag[i] = -1;
+#pragma omp for schedule(dynamic, 1)
+    for (int b = 0; b < n_blocks; ++b) {
+      const int r0 = bptr[b], r1 = bptr[b + 1];
+      for (int i = r0; i < r1; ++i) {
+        int diag = -1;
+        for (int k = rp[i]; k < rp[i + 1]; ++k) {
+          const int j = ci[k];
+          if (j < r0 || j >= r1) continue;
+          out[k] = vals[k];
+          colflag[j - r0] = k;
+          if (j == i) diag = k;
+        }
+        if (diag < 0) {
+          fprintf(stderr, "nsx_oracle: ILU row %d has no diagonal entry\n", i);
+          abort();
+        }
+        for (int kk = rp[i]; kk < rp[i + 1]; ++kk) {
+          const int j = ci[kk];
+          if (j < r0 || j >= i) continue; /* L part, ascending columns */
+          const double multiplier = out[kk];
+          /* find diagonal of row j */
+          const int dj = row_find(rp, ci, j, j);
+          out[kk] *= out[dj]; /* InV[jj] *= DV[j] */
+          for (int ku = dj + 1; ku < rp[j + 1]; ++ku) { /* U row of j (already scaled) */
+            const int c = ci[ku];
+            if (c >= r1) break;
+            const int pos = colflag[c - r0];
+            if (pos >= 0) out[pos] -= multiplier * out[ku];
+          }
+        }
+        out[diag] = 1.0 / out[diag];
+        for (int k = diag + 1; k < rp[i + 1]; ++k) {
+          if (ci[k] >= r1) break;
+          out[k] *= out[diag];
+        }
+        for (int k = rp[i]; k < rp[i + 1]; ++k) {
+          const int j = ci[k];
+          if (j >= r0 && j < r1) colflag[j - r0] = -1;
         }
       }
-      out[diag] = 1.0 / out[diag];
-      for (int k = diag + 1; k < rp[i + 1]; ++k) {
-        if (ci[k] >= r1) break;
-        out[k] *= out[diag];
-      }
-      for (int k = rp[i]; k < rp[i + 1]; ++k) {
-        const int j = ci[k];
-        if (j >= r0 && j < r1) colflag[j] = -1;
-      }
     }
+    free(colflag);
   }
-  free(colflag);
 }
 
 /* Ifpack_ILU::ApplyInverse: L solve (unit), D scaling, U solve (unit) [lib]. */
 void orc_ilu0_solve(int n_rows, const int32_t *rp, const int32_t *ci, const double *lu, int n_blocks,
                     const int32_t *bptr, const double *b, double *x) {
   (void)n_rows;
-  for (int blk = 0; blk < n_blocks; ++blk) {
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int blk = 0; blk < n_blocks; ++blk) { /* one block per MPI rank: independent */
     const int r0 = bptr[blk], r1 = bptr[blk + 1];
     for (int i = r0; i < r1; ++i) {
       double s = b[i];
@@ -272,6 +347,10 @@ void orc_ilu0_solve(int n_rows, const int32_t *rp, const int32_t *ci, const doub
 orc *orc_create(int dim, int n_cells, int dpc, int n_u, int n_p, const int32_t *cell_dofs, const double *cell_coords,
                 int n_q, int n_p2, int n_p1, const double *N2, const double *dN2, const double *N1, const double *weights,
                 const int32_t *const rowptr[4], const int32_t *const colind[4], double nu, double deltat) {
+  /* Krylov temporaries (megabytes each) are allocated and freed in every inner solve, as deal.II's GrowingVectorMemory
+   * pool hands them out in the reference; keep them in the heap instead of mmap/munmap + fresh page faults each time */
+  mallopt(M_MMAP_THRESHOLD, 1 << 30);
+  mallopt(M_TRIM_THRESHOLD, 1 << 30);
   orc *o = xcalloc(1, sizeof(orc));
   o->dim = dim;
   o->n_cells = n_cells;
@@ -448,7 +527,8 @@ static void block_add(orc *o, double *const blk[3], const int32_t *dofs, const d
         fprintf(stderr, "nsx_oracle: entry (%d,%d) not in sparsity pattern of block %d\n", r, c, b);
         abort();
       }
-      blk[b][pos] += v;
+#pragma omp atomic
+      blk[b][pos] += v; /* concurrent cells share rows: the sum-into of Epetra_FECrsMatrix, any order */
     }
   }
 }
@@ -494,16 +574,6 @@ static void fe_reinit(const orc *o, int cell, double *JxW, double *gradN2 /*[q][
 static void assemble_impl(orc *o, int first, int flags) {
   const int dim = o->dim, n = o->dpc, n_q = o->n_q;
   const double nu = o->nu, deltat = o->dt;
-  double *cell_matrix = xmalloc((size_t)n * n * sizeof(double));
-  double *cell_mass = xmalloc((size_t)n * n * sizeof(double));
-  double *cell_stiff = xmalloc((size_t)n * n * sizeof(double));
-  double *cell_conv = xmalloc((size_t)n * n * sizeof(double));
-  double *cell_pmass = xmalloc((size_t)n * n * sizeof(double));
-  double *cell_rhs = xmalloc((size_t)n * sizeof(double));
-  double *JxW = xmalloc((size_t)n_q * sizeof(double));
-  double *gradN2 = xmalloc((size_t)n_q * o->np2 * dim * sizeof(double));
-  double *cur_val = xmalloc((size_t)n_q * dim * sizeof(double));
-  double *cur_div = xmalloc((size_t)n_q * sizeof(double));
   const size_t nnz[3] = {(size_t)o->rp[0][o->n_u], (size_t)o->rp[1][o->n_u], (size_t)o->rp[2][o->n_p]};
 
   if (first) { /* NS3D:191-196 */
@@ -515,12 +585,28 @@ static void assemble_impl(orc *o, int first, int flags) {
     }
     memset(o->pmass, 0, (size_t)o->rp[3][o->n_p] * sizeof(double));
   } else { /* NS3D:388,395 */
-    for (int b = 0; b < 3; ++b)
+    for (int b = 0; b < 3; ++b) {
+#pragma omp parallel for schedule(static)
       for (size_t k = 0; k < nnz[b]; ++k) o->sys[b][k] += -1. * o->conv[b][k];
+    }
     for (int b = 0; b < 3; ++b) memset(o->conv[b], 0, nnz[b] * sizeof(double));
   }
   v_zero(o->n_u + o->n_p, o->rhs); /* NS3D:195,396 */
 
+  /* the cell loop: every MPI rank of the reference walks its own cells; here threads share the loop */
+#pragma omp parallel
+  {
+  double *cell_matrix = xmalloc((size_t)n * n * sizeof(double));
+  double *cell_mass = xmalloc((size_t)n * n * sizeof(double));
+  double *cell_stiff = xmalloc((size_t)n * n * sizeof(double));
+  double *cell_conv = xmalloc((size_t)n * n * sizeof(double));
+  double *cell_pmass = xmalloc((size_t)n * n * sizeof(double));
+  double *cell_rhs = xmalloc((size_t)n * sizeof(double));
+  double *JxW = xmalloc((size_t)n_q * sizeof(double));
+  double *gradN2 = xmalloc((size_t)n_q * o->np2 * dim * sizeof(double));
+  double *cur_val = xmalloc((size_t)n_q * dim * sizeof(double));
+  double *cur_div = xmalloc((size_t)n_q * sizeof(double));
+#pragma omp for schedule(static)
   for (int cell = 0; cell < o->n_cells; ++cell) { /* NS3D:208,420 (all cells are "locally owned" here) */
     const int32_t *dofs = o->cell_dofs + (size_t)cell * n;
     fe_reinit(o, cell, JxW, gradN2);
@@ -597,26 +683,20 @@ static void assemble_impl(orc *o, int first, int flags) {
     }
     block_add(o, o->conv, dofs, cell_conv);      /* NS3D:308,500 */
     if (first) block_add(o, o->stiff, dofs, cell_stiff); /* NS3D:309 */
-    for (int i = 0; i < n; ++i) o->rhs[dofs[i]] += cell_rhs[i]; /* NS3D:310,501 */
+    for (int i = 0; i < n; ++i) { /* NS3D:310,501 */
+#pragma omp atomic
+      o->rhs[dofs[i]] += cell_rhs[i];
+    }
     if (first) { /* pressure_mass.add (NS3D:311): only (p,p) entries are non-zero */
       for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j) {
           const double v = cell_pmass[i * n + j];
           if (v == 0.0) continue;
           const int pos = row_find(o->rp[3], o->ci[3], dofs[i] - o->n_u, dofs[j] - o->n_u);
+#pragma omp atomic
           o->pmass[pos] += v;
         }
     }
-  }
-  if (first) { /* NS3D:322-324 */
-    for (int b = 0; b < 3; ++b) {
-      for (size_t k = 0; k < nnz[b]; ++k) o->sys[b][k] += 1. * o->mass[b][k];
-      for (size_t k = 0; k < nnz[b]; ++k) o->sys[b][k] += 1. * o->conv[b][k];
-      for (size_t k = 0; k < nnz[b]; ++k) o->sys[b][k] += 1. * o->stiff[b][k];
-    }
-  } else { /* NS3D:512 */
-    for (int b = 0; b < 3; ++b)
-      for (size_t k = 0; k < nnz[b]; ++k) o->sys[b][k] += 1. * o->conv[b][k];
   }
   free(cell_matrix);
   free(cell_mass);
@@ -628,6 +708,22 @@ static void assemble_impl(orc *o, int first, int flags) {
   free(gradN2);
   free(cur_val);
   free(cur_div);
+  } /* omp parallel */
+  if (first) { /* NS3D:322-324 */
+    for (int b = 0; b < 3; ++b) {
+#pragma omp parallel for schedule(static)
+      for (size_t k = 0; k < nnz[b]; ++k) o->sys[b][k] += 1. * o->mass[b][k];
+#pragma omp parallel for schedule(static)
+      for (size_t k = 0; k < nnz[b]; ++k) o->sys[b][k] += 1. * o->conv[b][k];
+#pragma omp parallel for schedule(static)
+      for (size_t k = 0; k < nnz[b]; ++k) o->sys[b][k] += 1. * o->stiff[b][k];
+    }
+  } else { /* NS3D:512 */
+    for (int b = 0; b < 3; ++b) {
+#pragma omp parallel for schedule(static)
+      for (size_t k = 0; k < nnz[b]; ++k) o->sys[b][k] += 1. * o->conv[b][k];
+    }
+  }
 }
 
 void orc_assemble(orc *o, int flags) { assemble_impl(o, 1, flags); }
@@ -645,7 +741,8 @@ void orc_add_rhs(orc *o, int n, const int32_t *dofs, const double *vals) {
 void orc_apply_boundary_values(orc *o, int n, const int32_t *dofs, const double *vals) {
   const int32_t *rp = o->rp[0], *ci = o->ci[0];
   double *F = o->sys[0], *G = o->sys[1];
-  for (int r = 0; r < o->n_ranks; ++r) {
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int r = 0; r < o->n_ranks; ++r) { /* every rank handles the constrained rows of its own range */
     const int lo = o->rank_u[r], hi = o->rank_u[r + 1];
     double first_nonzero_diag = 1;
     for (int i = lo; i < hi; ++i) {
@@ -774,6 +871,7 @@ static sc_result cg(op_fn A, void *actx, double *x, const double *b, op_fn P, vo
     A(actx, g, x);
     v_add(n, g, -1., b);
   } else {
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < n; ++i) g[i] = -b[i];
   }
   double r = v_norm(n, g);
@@ -781,6 +879,7 @@ static sc_result cg(op_fn A, void *actx, double *x, const double *b, op_fn P, vo
   conv = sc_check(0, r, tol, maxiter);
   if (conv == 0) {
     P(pctx, h, g);
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < n; ++i) d[i] = -h[i];
     gh = v_dot(n, g, h);
     while (conv == 0) {
@@ -834,6 +933,7 @@ static void op_ilu(void *c, double *dst, const double *src) {
 void orc_system_vmult(orc *o, double *dst, const double *src) {
   const int n_u = o->n_u, n_p = o->n_p;
   orc_spmv(n_u, o->rp[0], o->ci[0], o->sys[0], src, dst);
+#pragma omp parallel for schedule(static)
   for (int i = 0; i < n_u; ++i) {
     double s = 0;
     for (int k = o->rp[1][i]; k < o->rp[1][i + 1]; ++k) s += o->sys[1][k] * src[n_u + o->ci[1][k]];
@@ -867,6 +967,7 @@ void orc_prec_initialize(orc *o, int type) {
   const double *F = o->sys[0], *M = o->mass[0];
   const double *V = NULL;
   if (type == ORC_YOSIDA) { /* Prec:350-358 */
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < n_u; ++i) {
       const double m = M[row_find(rp, ci, i, i)];
       o->diag_D_inv[i] = 1.0 / m;
@@ -874,6 +975,7 @@ void orc_prec_initialize(orc *o, int type) {
     }
     V = o->neg_diag_D_inv;
   } else if (type == ORC_SIMPLE || type == ORC_ASIMPLE) { /* Prec:135-144, 239-248 */
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < n_u; ++i) {
       const double temp = F[row_find(rp, ci, i, i)];
       o->diag_D[i] = temp;
@@ -882,6 +984,7 @@ void orc_prec_initialize(orc *o, int type) {
     }
     V = o->neg_diag_D_inv;
   } else { /* aYosida, Prec:447-468 */
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < n_u; ++i) {
       const double temp = F[row_find(rp, ci, i, i)];
       o->diag_D[i] = temp;

@@ -23,6 +23,11 @@ extern "C" {
 
 typedef struct orc orc;
 
+/* liboracle.so is serial (orc_threads() == 1); liboracle_mt.so is the same source built with -fopenmp: the loops the
+ * reference spreads over MPI ranks run on OpenMP threads (bench.py's "all host cores" CPU baseline). */
+int orc_threads(void);
+void orc_set_threads(int n);
+
 enum { ORC_TEMAM = 1, ORC_DOUBLE_CONVECTION = 2 };
 enum { ORC_YOSIDA = 0, ORC_SIMPLE = 1, ORC_AYOSIDA = 2, ORC_ASIMPLE = 3 };
 
