@@ -177,7 +177,7 @@ def cpu_step_from_state(dofs, tables, x, t_state, threads):
             "untimed_create_s": t_create, "untimed_first_assembly_s": t_first}
 
 
-def cpu_baseline(gpu_dofs, gpu_state, device, small_level=3):
+def cpu_baseline(gpu_dofs, gpu_state, device, small_level=5):
     """The stated CPU baseline, timed on this box's host cores in this run:
     (i) ALL usable cores on the bench workload itself (same mesh, same state, R = cores ranks as `mpirun -n cores` of
         the reference would have, first-touch numbering): oracle/liboracle_mt.so, the oracle's source built with OpenMP;
@@ -198,8 +198,8 @@ def cpu_baseline(gpu_dofs, gpu_state, device, small_level=3):
            "untimed_setup_s": {"orc_create": r["untimed_create_s"], "first_assembly": r["untimed_first_assembly_s"]}}
     del mesh, dofs
     # (ii) one core, reference-shaped, bounded sample.  A short GPU run on that small mesh provides the state to start from
-    # (64 virtual ranks there: the state depends on the layout only through the solver tolerance)
-    _, gd, gt = build_problem(small_level, 64, 1, "colour")
+    # (512 virtual ranks there: the state depends on the layout only through the solver tolerance)
+    _, gd, gt = build_problem(small_level, 512, 1, "colour")
     e2, _, _, _, s_state = gpu_run(gd, gt, 3, 1, 0, device, profile_steps=0, want_state=True)
     _, sd, st = build_problem(small_level, 1, 1, "first_touch")
     r1 = cpu_step_from_state(sd, st, transfer_state(gd, s_state[0], sd), s_state[1], 1)
@@ -207,7 +207,7 @@ def cpu_baseline(gpu_dofs, gpu_state, device, small_level=3):
                        "sample": "the same step on the %d-DoF mesh (level %d), 1 rank (the serial reference's layout), oracle/nsx_oracle.c "
                                  "gcc -O3, %d outer / %d inner-F iterations" % (sd.n_dofs, small_level, r1["outer"], r1["inner_F"]),
                        "sample_dofs": sd.n_dofs, "sample_seconds": r1["seconds"],
-                       "gpu_same_mesh_64_virtual_ranks_steps_per_s": 3 / e2}
+                       "gpu_same_mesh_512_virtual_ranks_steps_per_s": 3 / e2}
     return out
 
 

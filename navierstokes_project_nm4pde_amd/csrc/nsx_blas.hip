@@ -374,7 +374,7 @@ static void mgs_setup(nsx_handle *h) {
   if (getenv("NSX_DEBUG")) fprintf(stderr, "[nsx] mgs sweep: %d CUs x %d resident workgroups, grid <= %d\n", cus, per_cu, h->mgs_max_wg);
 }
 
-static void wait_published(nsx_handle *h, unsigned long long seq) {
+void wait_published(nsx_handle *h, unsigned long long seq) {
   volatile unsigned long long *flag_host = (volatile unsigned long long *)(h->pub_host + N_SLOTS);
   unsigned long long spins = 0;
   // sequence numbers only grow: a later publication that has already landed also proves this one did

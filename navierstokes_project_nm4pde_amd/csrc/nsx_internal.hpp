@@ -220,6 +220,11 @@ struct nsx_handle {
   bool sched_dirty = true;  // the ILU schedules do not match the current rank tables yet
   int mgs_used_wg[2] = {0, 0}, mgs_used_steps[2] = {0, 0};  // what the last launch on each region filled
   int mgs_parity = 0, mgs_max_wg = 0;  // mgs_max_wg = 0: cooperative launch unavailable, the launch-per-step chain is used
+  // persistent Schur-complement CG (nsx_cg.hip: k_cg_schur): mailbox regions, work vectors (d double-buffered, h)
+  nsx::DevBuf<unsigned long long> cg_box;
+  nsx::DevBuf<double> cg_vec;
+  int cg_parity = 0, cg_max_wg = 0;
+  bool cg_disabled = false;
   // ---- force evaluation (compute_forces): obstacle faces + face-quadrature tables
   int ff_n = 0, ff_nq = 0;
   nsx::DevBuf<int32_t> ff_cells, ff_lf;
@@ -339,6 +344,9 @@ double read_scalar(nsx_handle *h, int slot);
 void read_scalars(nsx_handle *h, int slot0, int count, double *out);
 unsigned long long publish_scalars(nsx_handle *h, int slot0, int count);  // asynchronous half of read_scalars
 void collect_published(nsx_handle *h, unsigned long long seq, int slot0, int count, double *out);
+void wait_published(nsx_handle *h, unsigned long long seq);  // host waits for the sequence number of a publication
+// persistent CG on the Schur complement (nsx_cg.hip); false: not applicable here, use the launch-per-operation solver
+bool cg_schur_persistent(nsx_handle *h, double *x, const double *b, double rtol, int maxiter, int *steps, double *last, int *status);
 void write_scalar(nsx_handle *h, int slot, double v);
 
 // solver (nsx_solve.hip)

@@ -275,6 +275,14 @@ void prec_vmult(nsx_handle *h, int type, double tol, int maxit, double *dst, con
   Op PF = [h, dim](double *d, const double *s) { ilu_solve(h, h->gA, h->schedF, h->luF.p, s, d, dim, "ilu_solve_F"); };
   Op PS = [h](double *d, const double *s) { ilu_solve(h, h->gS, h->schedS, h->luS.p, s, d, 1, "ilu_solve_S"); };
   OpDot PSdot = [h](double *d, const double *s, int slot) { return ilu_solve(h, h->gS, h->schedS, h->luS.p, s, d, 1, "ilu_solve_S", slot); };
+  // SolverCG on negative_S_tilde with tolerance tol * |b| (Prec.hpp:179-182,388-390,500-502): one persistent launch where the
+  // layout allows it (nsx_cg.hip), else the launch-per-operation solver above
+  auto cg_S = [&](double *x, const double *b) {
+    int steps = 0, status = 0;
+    double last = 0.0;
+    if (cg_schur_persistent(h, x, b, tol, maxit, &steps, &last, &status)) return SolveResult{status, steps, last};
+    return cg(h, Sm, x, b, PS, n_p, len_p, tol * norm2(h, n_p, b), maxit, &PSdot);
+  };
 
   if (type == NSX_PREC_YOSIDA) {  // Prec.hpp:365-408
     Tmp yu(h, len_u), yp(h, len_p), tmp(h, len_p), tmp2(h, len_u), res(h, len_u);
@@ -283,7 +291,7 @@ void prec_vmult(nsx_handle *h, int type, double tol, int maxit, double *dst, con
     count(st, true, gmres(h, Fm, yu.p(), src_u, PF, n_u, len_u, tol * norm2(h, n_u, src_u), maxit)); // :371-382
     spmv_B(h, yu.p(), tmp.p());                                                               // :385
     v_add(h, n_p, tmp.p(), -1.0, src_p);                                                      // :386
-    count(st, false, cg(h, Sm, yp.p(), tmp.p(), PS, n_p, len_p, tol * norm2(h, n_p, tmp.p()), maxit, &PSdot));  // :388-390
+    count(st, false, cg_S(yp.p(), tmp.p()));                                                  // :388-390
     v_copy(h, n_p, dst_p, yp.p());                                                            // :394
     spmv_G(h, dst_p, tmp2.p(), false);                                                        // :398
     v_zero(h, n_u, res.p());                                                                  // :401
@@ -297,7 +305,7 @@ void prec_vmult(nsx_handle *h, int type, double tol, int maxit, double *dst, con
     count(st, true, gmres(h, Fm, sol1_u.p(), src_u, PF, n_u, len_u, tol * norm2(h, n_u, src_u), maxit));  // :157-173
     spmv_B(h, sol1_u.p(), temp_1.p());                                                             // :175
     v_add(h, n_p, temp_1.p(), -1.0, src_p);                                                        // :176
-    count(st, false, cg(h, Sm, sol1_p.p(), temp_1.p(), PS, n_p, len_p, tol * norm2(h, n_p, temp_1.p()), maxit, &PSdot));  // :179-182
+    count(st, false, cg_S(sol1_p.p(), temp_1.p()));                                               // :179-182
     v_copy(h, n_p, dst_p, sol1_p.p());                                                             // :194
     v_scale(h, n_p, dst_p, 1. / 0.5);                                                              // :195, alpha = 0.5 (:207)
     v_copy(h, n_u, dst_u, sol1_u.p());                                                             // :199
@@ -324,7 +332,7 @@ void prec_vmult(nsx_handle *h, int type, double tol, int maxit, double *dst, con
     v_copy(h, n_u, yu.p(), tmp.p());                  // :493
     spmv_B(h, tmp.p(), tmp2.p());                     // :496
     v_sadd(h, n_p, yp.p(), -1.0, 1.0, tmp2.p());      // :497
-    count(st, false, cg(h, Sm, dst_p, yp.p(), PS, n_p, len_p, tol * norm2(h, n_p, yp.p()), maxit, &PSdot));  // :500-502
+    count(st, false, cg_S(dst_p, yp.p()));          // :500-502
     v_copy(h, n_p, yp.p(), dst_p);                    // :504
     spmv_F(h, h->vF.p, yu.p(), t.p());                // :507 F->vmult(yu,yu): Epetra multiplies out of place when the arguments alias
     v_copy(h, n_u, yu.p(), t.p());

@@ -127,3 +127,41 @@ def test_gram_schmidt_as_one_launch_equals_the_launch_per_link_chain(prob):
     for key in ("outer_iterations", "inner_F_iterations", "inner_S_iterations"):
         assert abs(s0[key] - s1[key]) <= max(1, 0.02 * s0[key]), key
     assert np.abs(x0 - x1).max() < 1e-9 * np.abs(x0).max()
+
+
+def test_schur_cg_as_one_launch_equals_the_launch_per_operation_solver():
+    """NSX_CG_PERSISTENT=0 runs SolverCG on negative_S_tilde as separate launches (SpMV, dot, update, ILU, axpby): the
+    persistent kernel k_cg_schur must walk through the same iteration history and end at the same vector."""
+    p = Problem("cylinder", 3, 2, n_sub=24, ordering="colour")
+    res = []
+    for flag in ("0", "1"):
+        os.environ["NSX_CG_PERSISTENT"] = flag
+        try:
+            dev, _ = _assembled(p)
+            dev.prec_initialize(0)
+            src = np.random.default_rng(3).standard_normal(p.dofs.n_dofs)
+            y, st = dev.prec_vmult(0, src, inner_rtol=1e-10)
+            t = dev.solve_time_step(0)  # reference tolerances: many short CG solves in a row (mailbox ring, region swap)
+            res.append((st, y, t, dev.solution_owned.copy()))
+            dev.close()
+        finally:
+            os.environ.pop("NSX_CG_PERSISTENT", None)
+    (s0, y0, t0, x0), (s1, y1, t1, x1) = res
+    assert s0["status"] == 0 and s1["status"] == 0
+    assert s0["inner_S_iterations"] > 10 and abs(s0["inner_S_iterations"] - s1["inner_S_iterations"]) <= 1
+    assert np.abs(y0 - y1).max() < 1e-8 * np.abs(y0).max()
+    for key in ("outer_iterations", "inner_S_iterations"):
+        assert abs(t0[key] - t1[key]) <= max(1, 0.05 * t0[key]), key
+    assert np.abs(x0 - x1).max() < 1e-3 * np.abs(x0).max()
+
+
+def test_schur_cg_persistent_kernel_is_the_one_that_runs():
+    """the persistent launch shows up in the handle's kernel table (and the per-operation kernels of CG do not)"""
+    p = Problem("cylinder", 3, 2, n_sub=24, ordering="colour")
+    dev, _ = _assembled(p)
+    dev.profile(True)
+    dev.solve_time_step(0)
+    table = dev.profile_table()
+    dev.close()
+    assert table.get("cg_S", {}).get("launches", 0) > 0
+    assert table.get("cg_update", {}).get("launches", 0) == 0
