@@ -8,7 +8,7 @@
 // device.  Everything is deterministic: fixed grids, fixed-order sums, no atomics.
 // Multi-GPU: every rank leaves the same number of partial sums, they are all-reduced element-wise over RCCL
 // (comm_allreduce_partials) and consumed exactly as on one GPU.
-#include "nsx_internal.hpp"
+#include "nsx_grid.hpp"
 
 namespace nsx {
 
@@ -211,65 +211,31 @@ void v_add_and_dot(nsx_handle *h, Span sp, double *d, double a, int aslot, const
 // deal.II's SolverGMRES orthogonalises the new Krylov vector w with the chain  h(0) = w.v_0 ;
 // h(i+1) = w.add_and_dot(-h(i), v_i, v_{i+1}) ; |w|^2 = w.add_and_dot(-h(dim-1), v_{dim-1}, w): dim+1 dependent global
 // reductions.  As separate launches every link streams w (read + write) and two basis vectors, 32 B per entry; here the
-// grid is co-resident (cooperative launch), every thread keeps its entries of w and of the current v_i in registers for
-// the whole sweep, and a link costs ONE read of the next basis vector (8 B per entry, prefetched before the wait) plus a
-// grid-wide exchange of the partial sums.  The exchange uses no atomics on shared counters: workgroup b stores the bit
-// pattern of its partial sum in mailbox[step][b] (initially MGS_EMPTY), workgroup 0 waits for all of them, adds them in
-// a fixed order and stores the total in total[step], where every workgroup picks it up.  The arithmetic of each entry is
-// that of the chain (w += (-h) v_i), sums are fixed-order, so results do not depend on timing.
-// Every wait is bounded by a wall-clock timeout that raises *err, so the grid always drains.
-constexpr int MGS_E = 10;         // entries of w per thread
+// grid is co-resident, every thread keeps its entries of w and of the current v_i in registers for the whole sweep, and a
+// link costs ONE read of the next basis vector (8 B per entry, prefetched before the wait) plus a grid-wide exchange of
+// the partial sums (nsx_grid.hpp: mailboxes, no atomics on shared counters).  Two exchange shapes:
+//   MODE 0  workgroup 0 waits for all mailboxes, adds them in a fixed order and publishes the total, which every
+//           workgroup picks up (two hops through memory, 1 + nwg polled words per workgroup);
+//   MODE 1  every workgroup reads all mailboxes itself and adds them in the same fixed order (one hop, nwg polled words
+//           per workgroup; every workgroup computes bit-identical totals).
+// The arithmetic of each entry is that of the chain (w += (-h) v_i), sums are fixed-order, so results do not depend on
+// timing.  Every wait is bounded by a wall-clock timeout: a grid that is not co-resident (another stream or process holds
+// compute units) ends without touching w, and the host falls back to the launch-per-link chain (v_mgs).
 constexpr int MGS_MAX_WG = 512;
 constexpr int MGS_STEPS = 32;     // >= max_n_tmp_vectors + 1
-constexpr unsigned long long MGS_EMPTY = ~0ull;
 constexpr size_t MGS_REGION = (size_t)MGS_STEPS * MGS_MAX_WG + MGS_STEPS;  // words per mailbox region (+ the totals)
+// after the two mailbox regions: [0] error raised by a workgroup that timed out, [1] number of workgroups that wrote w back
+constexpr size_t MGS_TAIL = 2;
 
 struct MgsArgs {
   const double *v[MGS_STEPS];
 };
 
-__device__ __forceinline__ unsigned long long mgs_bits(double v) {
-  unsigned long long b = (unsigned long long)__double_as_longlong(v);
-  return b == MGS_EMPTY ? 0x7ff8000000000000ull : b;  // a NaN with the sentinel's bit pattern becomes the canonical NaN
-}
-__device__ __forceinline__ unsigned long long mgs_wait(const unsigned long long *p, int *err) {
-  unsigned long long b = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (b != MGS_EMPTY) return b;
-  const unsigned long long t0 = wall_clock64();  // 100 MHz
-  while ((b = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == MGS_EMPTY) {
-    __builtin_amdgcn_s_sleep(1);
-    if (wall_clock64() - t0 > 200000000ull) {  // 2 s: something is badly wrong; give up instead of hanging the GPU
-      *err = 1;
-      return 0;
-    }
-  }
-  return b;
-}
-// sum over the 64 lanes of the wave in a fixed order, result wave-uniform: four DPP stages inside each row of 16 lanes,
-// then the four row sums are read out of lanes 0/16/32/48
-__device__ __forceinline__ double mgs_wave_sum(double v) {
-  v += dpp_f64<0xB1>(v);
-  v += dpp_f64<0x4E>(v);
-  v += dpp_f64<0x141>(v);
-  v += dpp_f64<0x140>(v);
-  const int lo = __double2loint(v), hi = __double2hiint(v);
-  double r[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) r[k] = __hiloint2double(__builtin_amdgcn_readlane(hi, 16 * k), __builtin_amdgcn_readlane(lo, 16 * k));
-  return (r[0] + r[1]) + (r[2] + r[3]);
-}
-// fixed-order sum over the 256 threads of the block, result in every thread
-__device__ __forceinline__ double mgs_block_sum(double v, double *sh) {
-  v = mgs_wave_sum(v);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-  __syncthreads();
-  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
-}
-
+template <int E, int MODE>
 __global__ __launch_bounds__(256) void k_mgs(int n, int split, int gap, double *__restrict__ w, MgsArgs V, int dim,
                                              unsigned long long *box, unsigned long long *box_next, int reset_wg, int reset_steps,
-                                             double *__restrict__ scal_out, int *err, int normalize, int consider, double *pub_vals,
-                                             unsigned long long *pub_flag, unsigned long long seq) {
+                                             double *__restrict__ scal_out, int *err_host, unsigned int *tail, int normalize, int consider,
+                                             double *pub_vals, unsigned long long *pub_flag, unsigned long long seq) {
   __shared__ double sh[2][4];  // two buffers: a wave may start the next sum while a slower one still reads this one
   __shared__ unsigned long long bc;
   __shared__ double tots[MGS_STEPS];
@@ -277,12 +243,12 @@ __global__ __launch_bounds__(256) void k_mgs(int n, int split, int gap, double *
   unsigned long long *total = box + (size_t)MGS_STEPS * MGS_MAX_WG, *total_next = box_next + (size_t)MGS_STEPS * MGS_MAX_WG;
   // leave the other region empty for the next launch (stream order makes this visible to it): its last user filled
   // reset_steps rows of reset_wg mailboxes, possibly more than this grid has workgroups
-  for (int q = t; q < reset_steps * reset_wg; q += T) box_next[(size_t)(q / reset_wg) * MGS_MAX_WG + q % reset_wg] = MGS_EMPTY;
-  if (wg == 0 && threadIdx.x < MGS_STEPS) total_next[threadIdx.x] = MGS_EMPTY;
-  double wv[MGS_E], vc[MGS_E], vn[MGS_E];
-  int idx[MGS_E];
+  for (int q = t; q < reset_steps * reset_wg; q += T) box_next[(size_t)(q / reset_wg) * MGS_MAX_WG + q % reset_wg] = GX_EMPTY;
+  if (wg == 0 && threadIdx.x < MGS_STEPS) total_next[threadIdx.x] = GX_EMPTY;
+  double wv[E], vc[E], vn[E];
+  int idx[E];
 #pragma unroll
-  for (int k = 0; k < MGS_E; ++k) {
+  for (int k = 0; k < E; ++k) {
     const int i0 = t + k * T;
     idx[k] = i0 < n ? i0 + (i0 >= split ? gap : 0) : -1;
     wv[k] = idx[k] >= 0 ? w[idx[k]] : 0.0;
@@ -292,37 +258,50 @@ __global__ __launch_bounds__(256) void k_mgs(int n, int split, int gap, double *
   // consider: SolverGMRES' re-orthogonalisation test (every 5th inner iteration) needs |w| BEFORE the sweep: one more link
   // in front (mailbox row dim + 1), and the decision whether w may be normalised is taken here exactly as the host takes it
   double norm0_sq = 0.0;
+  int lerr = 0;
+  bool dead = false;
   for (int s = consider ? -1 : 0; s <= dim; ++s) {
     const bool pre = s < 0;
     const int ri = pre ? dim + 1 : s;
     double acc = 0.0;
 #pragma unroll
-    for (int k = 0; k < MGS_E; ++k) acc += wv[k] * ((!pre && s < dim) ? vc[k] : wv[k]);
+    for (int k = 0; k < E; ++k) acc += wv[k] * ((!pre && s < dim) ? vc[k] : wv[k]);
     if (!pre && s + 1 < dim) {  // the next basis vector is on its way while the sums are exchanged
       const double *__restrict__ vp = V.v[s + 1];
 #pragma unroll
-      for (int k = 0; k < MGS_E; ++k) vn[k] = idx[k] >= 0 ? vp[idx[k]] : 0.0;
+      for (int k = 0; k < E; ++k) vn[k] = idx[k] >= 0 ? vp[idx[k]] : 0.0;
     }
-    const double part = mgs_block_sum(acc, sh[0]);
+    const double part = gx_block_sum(acc, sh[0]);
     unsigned long long *row = box + (size_t)ri * MGS_MAX_WG;
-    if (threadIdx.x == 0) __hip_atomic_store(row + wg, mgs_bits(part), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // workgroup 0 collects the partial sums, adds them in a fixed order and publishes the total; the others wait for
-    // that one word (letting every workgroup read all mailboxes saves a trip through memory on paper but measured
-    // slower: 64 us against 57 us per sweep of 9 links at 1.04 M entries, the polling traffic gets in its own way)
-    if (wg == 0) {
-      double a = 0.0, b = 0.0;
-      if ((int)threadIdx.x < nwg) a = __longlong_as_double((long long)mgs_wait(row + threadIdx.x, err));
-      if ((int)threadIdx.x + 256 < nwg) b = __longlong_as_double((long long)mgs_wait(row + threadIdx.x + 256, err));
-      const double tot = mgs_block_sum(a + b, sh[1]);
-      if (threadIdx.x == 0) {
-        scal_out[ri] = tot;
-        __hip_atomic_store(total + ri, mgs_bits(tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        tots[ri] = tot;
+    if (threadIdx.x == 0) gx_post(row + wg, part);
+    double hs;
+    if (MODE == 0) {
+      if (wg == 0) {
+        double a = 0.0;
+        for (int q = threadIdx.x; q < nwg; q += 256) a += gx_wait_value(row + q, &lerr);
+        const double tot = gx_block_sum(a, sh[1]);
+        // a total built on a timed-out mailbox must never go out: the others then time out as well and nobody writes w
+        const int bad = __syncthreads_or(lerr);
+        if (threadIdx.x == 0 && !bad) {
+          scal_out[ri] = tot;
+          gx_post(total + ri, tot);
+          tots[ri] = tot;
+        }
+      }
+      if (threadIdx.x == 0) bc = gx_wait(total + ri, &lerr);
+      dead = __syncthreads_or(lerr) != 0;
+      hs = __longlong_as_double((long long)bc);
+    } else {
+      double a = 0.0;
+      for (int q = threadIdx.x; q < nwg; q += 256) a += gx_wait_value(row + q, &lerr);
+      hs = gx_block_sum(a, sh[1]);
+      dead = __syncthreads_or(lerr) != 0;
+      if (wg == 0 && threadIdx.x == 0 && !dead) {
+        scal_out[ri] = hs;
+        tots[ri] = hs;
       }
     }
-    if (threadIdx.x == 0) bc = mgs_wait(total + ri, err);
-    __syncthreads();
-    const double hs = __longlong_as_double((long long)bc);
+    if (dead) break;
     if (pre) {
       norm0_sq = hs;
       continue;
@@ -330,7 +309,7 @@ __global__ __launch_bounds__(256) void k_mgs(int n, int split, int gap, double *
     if (s < dim) {
       const double alpha = -1.0 * hs;
 #pragma unroll
-      for (int k = 0; k < MGS_E; ++k) {
+      for (int k = 0; k < E; ++k) {
         wv[k] += alpha * vc[k];
         vc[k] = vn[k];
       }
@@ -341,9 +320,21 @@ __global__ __launch_bounds__(256) void k_mgs(int n, int split, int gap, double *
       if (nrm != 0.0 && !second_sweep) {
         const double inv = 1. / nrm;
 #pragma unroll
-        for (int k = 0; k < MGS_E; ++k) wv[k] = inv * wv[k];
+        for (int k = 0; k < E; ++k) wv[k] = inv * wv[k];
       }
     }
+  }
+  if (dead) {
+    // w stays as it was.  Tell the host (mapped word) and, from workgroup 0, wake it up
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(err_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(tail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (wg == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(pub_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    return;
   }
   // hand the coefficients to the host: values, then the flag it is polling, both in fine-grained mapped host memory.  The
   // stores are acknowledged (vmcnt) before the flag goes out; a system-scope release would also write back the whole L2.
@@ -354,24 +345,36 @@ __global__ __launch_bounds__(256) void k_mgs(int n, int split, int gap, double *
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(pub_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+  if (threadIdx.x == 0) atomicAdd(tail + 1, 1u);  // this workgroup commits its part of w
 #pragma unroll
-  for (int k = 0; k < MGS_E; ++k)
+  for (int k = 0; k < E; ++k)
     if (idx[k] >= 0) w[idx[k]] = wv[k];
 }
 
 static void mgs_setup(nsx_handle *h) {
-  if (h->mgs_box.p) return;
+  if (h->mgs_box.p || h->mgs_disabled) return;
   h->mgs_max_wg = 0;
-  if (getenv("NSX_MGS") && atoi(getenv("NSX_MGS")) == 0) return;
-  int coop = 0, cus = 0, per_cu = 0;
-  HIP_CHECK(hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, h->prm.device));
+  if (getenv("NSX_MGS") && atoi(getenv("NSX_MGS")) == 0) {
+    h->mgs_disabled = true;
+    return;
+  }
+  int cus = 0, per_cu = 0;
   HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->prm.device));
-  if (!coop) return;
-  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mgs, 256, 0));
-  h->mgs_box.alloc(2 * MGS_REGION);
+  int per_cu20 = 0;
+  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_mgs<10, 0>), 256, 0));
+  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu20, (k_mgs<20, 0>), 256, 0));
+  h->mgs_box.alloc(2 * MGS_REGION + MGS_TAIL);
   HIP_CHECK(hipMemsetAsync(h->mgs_box.p, 0xff, 2 * MGS_REGION * sizeof(unsigned long long), h->stream));
+  HIP_CHECK(hipMemsetAsync(h->mgs_box.p + 2 * MGS_REGION, 0, MGS_TAIL * sizeof(unsigned long long), h->stream));
   h->mgs_max_wg = std::min(MGS_MAX_WG, per_cu * cus);
-  if (getenv("NSX_DEBUG")) fprintf(stderr, "[nsx] mgs sweep: %d CUs x %d resident workgroups, grid <= %d\n", cus, per_cu, h->mgs_max_wg);
+  h->mgs_max_wg20 = std::min(MGS_MAX_WG, per_cu20 * cus);
+  if (getenv("NSX_MGS_MAXWG")) {
+    h->mgs_max_wg = std::max(1, std::min(h->mgs_max_wg, atoi(getenv("NSX_MGS_MAXWG"))));
+    h->mgs_max_wg20 = std::max(1, std::min(h->mgs_max_wg20, atoi(getenv("NSX_MGS_MAXWG"))));
+  }
+  h->mgs_mode = getenv("NSX_MGS_MODE") ? atoi(getenv("NSX_MGS_MODE")) : 0;
+  h->mgs_coop = getenv("NSX_MGS_COOP") && atoi(getenv("NSX_MGS_COOP")) != 0;
+  if (getenv("NSX_DEBUG")) fprintf(stderr, "[nsx] mgs sweep: %d CUs x %d resident workgroups, grid <= %d, exchange mode %d\n", cus, per_cu, h->mgs_max_wg, h->mgs_mode);
 }
 
 void wait_published(nsx_handle *h, unsigned long long seq) {
@@ -385,7 +388,33 @@ void wait_published(nsx_handle *h, unsigned long long seq) {
       break;
     }
   }
-  if (*(volatile int *)(h->pub_host + N_SLOTS + 2)) NSX_THROW(NSX_ERR_HIP, "Gram-Schmidt sweep: a workgroup waited more than 2 s for a partial sum");
+}
+
+// A persistent sweep ended on a timeout (its grid was not co-resident).  Put the handle back into a usable state: wait for the
+// stragglers, empty the mailboxes, clear the error words and use the launch-per-link chain from now on.  Returns how many
+// workgroups had already written their part of w (0: w is untouched and the sweep can simply be redone by the chain).
+static unsigned int mgs_recover(nsx_handle *h) {
+  HIP_CHECK(hipStreamSynchronize(h->stream));
+  unsigned long long tail[MGS_TAIL] = {0, 0};
+  HIP_CHECK(hipMemcpy(tail, h->mgs_box.p + 2 * MGS_REGION, sizeof(tail), hipMemcpyDeviceToHost));
+  HIP_CHECK(hipMemsetAsync(h->mgs_box.p, 0xff, 2 * MGS_REGION * sizeof(unsigned long long), h->stream));
+  HIP_CHECK(hipMemsetAsync(h->mgs_box.p + 2 * MGS_REGION, 0, MGS_TAIL * sizeof(unsigned long long), h->stream));
+  *(volatile int *)(h->pub_host + N_SLOTS + 2) = 0;
+  h->mgs_used_wg[0] = h->mgs_used_wg[1] = h->mgs_used_steps[0] = h->mgs_used_steps[1] = 0;
+  h->mgs_max_wg = h->mgs_max_wg20 = 0;
+  h->mgs_disabled = true;
+  const unsigned int committed = ((const unsigned int *)tail)[1] - h->mgs_commit_base;
+  h->mgs_commit_base = 0;
+  if (getenv("NSX_DEBUG")) fprintf(stderr, "[nsx] Gram-Schmidt sweep timed out (grid not co-resident): using one launch per link from now on\n");
+  return committed;
+}
+
+static void mgs_chain(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int slot0, double *out, bool consider) {
+  if (consider) v_dot(h, sp, w, w, slot0 + dim + 1);
+  v_dot(h, sp, w, vs[0], slot0);
+  for (int i = 1; i < dim; ++i) v_add_and_dot(h, sp, w, -1.0, slot0 + i - 1, vs[i - 1], vs[i], slot0 + i);
+  v_add_and_dot(h, sp, w, -1.0, slot0 + dim - 1, vs[dim - 1], w, slot0 + dim);
+  read_scalars(h, slot0, dim + 1 + (consider ? 1 : 0), out);
 }
 
 // out[0..dim) = h(i), out[dim] = |w|^2 after the sweep.  Returns true when w was also normalised (only if asked to).
@@ -393,14 +422,15 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
            const std::function<void()> *after_launch, bool consider) {
   const int n = sp.n;
   if (!h->comm) mgs_setup(h);
-  const int nwg = std::max(1, std::min(h->mgs_max_wg, cdiv(n, 256 * 4)));
-  if (h->comm || h->mgs_max_wg == 0 || dim + 2 > MGS_STEPS || (int64_t)nwg * 256 * MGS_E < n) {
+  int nwg = std::max(1, std::min(h->mgs_max_wg, cdiv(n, 256 * 4)));
+  int per_thread = cdiv(n, (int64_t)nwg * 256);
+  if (per_thread > 10) {  // the 20-entries-per-thread instantiation needs more registers: its own residency limit
+    nwg = std::max(1, std::min(h->mgs_max_wg20, cdiv(n, 256 * 4)));
+    per_thread = cdiv(n, (int64_t)nwg * 256);
+  }
+  if (h->comm || h->mgs_max_wg == 0 || dim + 2 > MGS_STEPS || per_thread > 20) {
     // one launch per link: the distributed solve needs an all-reduce after every dot product
-    if (consider) v_dot(h, sp, w, w, slot0 + dim + 1);
-    v_dot(h, sp, w, vs[0], slot0);
-    for (int i = 1; i < dim; ++i) v_add_and_dot(h, sp, w, -1.0, slot0 + i - 1, vs[i - 1], vs[i], slot0 + i);
-    v_add_and_dot(h, sp, w, -1.0, slot0 + dim - 1, vs[dim - 1], w, slot0 + dim);
-    read_scalars(h, slot0, dim + 1 + (consider ? 1 : 0), out);
+    mgs_chain(h, sp, w, dim, vs, slot0, out, consider);
     return false;
   }
   const unsigned long long seq = ++h->pub_seq;
@@ -413,16 +443,20 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
     unsigned long long *box = h->mgs_box.p + (size_t)h->mgs_parity * MGS_REGION, *box_next = h->mgs_box.p + (size_t)(1 - h->mgs_parity) * MGS_REGION;
     double *sout = h->scal.p + slot0, *pub_vals = h->pub_dev + slot0;
     unsigned long long *pub_flag = (unsigned long long *)(h->pub_dev + N_SLOTS), seq_ = seq;
-    int *err = (int *)(h->pub_dev + N_SLOTS + 2);  // mapped host word, checked by wait_published
+    int *err = (int *)(h->pub_dev + N_SLOTS + 2);  // mapped host word
+    unsigned int *tail = (unsigned int *)(h->mgs_box.p + 2 * MGS_REGION);
     int reset_wg = h->mgs_used_wg[1 - h->mgs_parity], reset_steps = h->mgs_used_steps[1 - h->mgs_parity];
-    void *args[] = {&n_, &split, &gap, &w, &V, &dim_, &box, &box_next, &reset_wg, &reset_steps, &sout, &err, &norm_, &consider_, &pub_vals, &pub_flag, &seq_};
-    // Co-residency: the grid never exceeds what the device holds at once (mgs_setup), the stream is in-order and nothing else
-    // runs on this queue, so a plain launch places every workgroup at once; hipLaunchCooperativeKernel guarantees it but
-    // goes through the device-wide cooperative queue, which costs ~20 us of cross-queue synchronisation per launch.
-    // Should a workgroup ever be missing, the bounded waits end the kernel after 2 s and the solve fails loudly.
-    static const bool coop = getenv("NSX_MGS_COOP") && atoi(getenv("NSX_MGS_COOP")) != 0;
-    if (coop) HIP_CHECK(hipLaunchCooperativeKernel((const void *)k_mgs, dim3(nwg), dim3(256), args, 0, h->stream));
-    else HIP_CHECK(hipLaunchKernel((const void *)k_mgs, dim3(nwg), dim3(256), args, 0, h->stream));
+    void *args[] = {&n_, &split, &gap, &w, &V, &dim_, &box, &box_next, &reset_wg, &reset_steps, &sout, &err, &tail, &norm_, &consider_, &pub_vals, &pub_flag, &seq_};
+    // Co-residency: the grid never exceeds what the device holds at once (mgs_setup), the stream is in-order and normally nothing
+    // else runs on the device, so a plain launch places every workgroup at once.  hipLaunchCooperativeKernel (NSX_MGS_COOP=1) adds
+    // a launch-time size check and ~20 us of cross-queue synchronisation per launch, but no residency guarantee beyond that
+    // (/opt/skills/guides/MI355X_MICROARCH.md, "Residency and cooperative launch").  What makes the sweep safe is the bounded wait:
+    // should a workgroup be missing (another stream or process holds compute units), the kernel ends without writing w and the
+    // sweep is redone by the launch-per-link chain below.
+    const void *fn = per_thread <= 10 ? (h->mgs_mode == 1 ? (const void *)k_mgs<10, 1> : (const void *)k_mgs<10, 0>)
+                                      : (h->mgs_mode == 1 ? (const void *)k_mgs<20, 1> : (const void *)k_mgs<20, 0>);
+    if (h->mgs_coop) HIP_CHECK(hipLaunchCooperativeKernel(fn, dim3(nwg), dim3(256), args, 0, h->stream));
+    else HIP_CHECK(hipLaunchKernel(fn, dim3(nwg), dim3(256), args, 0, h->stream));
     h->mgs_used_wg[h->mgs_parity] = nwg;
     h->mgs_used_steps[h->mgs_parity] = dim + 2;
     h->mgs_used_wg[1 - h->mgs_parity] = h->mgs_used_steps[1 - h->mgs_parity] = 0;
@@ -431,8 +465,19 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
   }
   // w is final (and normalised) once the kernel has run: work that only depends on it may be enqueued before the host
   // has the coefficients
-  if (normalize && !consider && after_launch) (*after_launch)();
+  const bool ran_ahead = normalize && !consider && after_launch;
+  if (ran_ahead) (*after_launch)();
   wait_published(h, seq);
+  if (*(volatile int *)(h->pub_host + N_SLOTS + 2)) {
+    const unsigned int committed = mgs_recover(h);
+    if (committed != 0) NSX_THROW(NSX_ERR_HIP, "Gram-Schmidt sweep: %u workgroups had written w when another one timed out", committed);
+    // what after_launch enqueued (the next operator application) used the unfinished w: its result is a temporary that the
+    // caller recomputes when told that w was not normalised here
+    mgs_chain(h, sp, w, dim, vs, slot0, out, consider);
+    if (ran_ahead) h->mgs_redo_ahead = true;
+    return false;
+  }
+  h->mgs_commit_base += (unsigned int)nwg;  // every workgroup of a finished sweep has committed its part of w
   for (int i = 0; i <= dim + (consider ? 1 : 0); ++i) out[i] = h->pub_host[slot0 + i];
   if (!normalize) return false;
   // the kernel's own decision, recomputed from the same two numbers

@@ -79,36 +79,110 @@ __device__ __forceinline__ bool cg_exchange(const double (&part)[NV], double (&t
   return dead == 0;
 }
 
-__global__ __launch_bounds__(256) void k_cg_schur(int n_blocks, const int32_t *__restrict__ bptr, const int32_t *__restrict__ rp,
-                                                  const int32_t *__restrict__ ci, const double *__restrict__ sv,
-                                                  const int64_t *__restrict__ dn_off, const double *__restrict__ P, const double *__restrict__ b,
-                                                  double *x, double *D0, double *D1, double *H, double rtol, int maxiter,
-                                                  unsigned long long *box, unsigned long long *box_other, double *pub_vals,
-                                                  unsigned long long *pub_flag, unsigned long long seq, int *err_dev) {
-  __shared__ double gs[CG_MAXB], hs[CG_MAXB], ds[CG_MAXB], hvs[CG_MAXB], xs[CG_MAXB];
+// ---- packed operator stream ------------------------------------------------------------------------------------------
+// A latency-bound kernel must not chase pointers: rowptr -> colind -> x is three dependent trips through memory per row.
+// At setup (build_cg_plan) the rows of every Schur block are laid out as slabs of 256 slots — slab (round r, chunk c) holds
+// entry 16c + lane of row 16r + grp for thread (grp, lane) — so every value load has an address that depends on the loop
+// counter alone and many slabs are in flight at once.  Columns are 16-bit indices into the block's list of unique columns,
+// whose d entries are staged in LDS once per iteration (~400 gathers per block instead of ~7000).
+constexpr int CG_PF = 8;         // slabs per register set (two sets in flight)
+constexpr int CG_MAX_UCOLS = 1024;
+
+__global__ void k_cg_pack(int64_t n_slots, const int32_t *__restrict__ src, const double *__restrict__ sv, double *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_slots) out[i] = src[i] >= 0 ? sv[src[i]] : 0.0;
+}
+
+// hv_q = sum_j S_qj xst[lidx]  for the rows of this block; 16 lanes per row, result in hvs[]
+__device__ __forceinline__ void cg_block_spmv(int s0, int s1, const double *__restrict__ sval, const uint16_t *__restrict__ slidx,
+                                              const int32_t *__restrict__ sinfo, const double *xst, double *hvs, int tid) {
+  const int grp = tid >> 4, lane = tid & 15;
+  double va[CG_PF], vb[CG_PF];
+  int la[CG_PF], lb[CG_PF];
+  double acc = 0.0;
+#define NSX_CG_LOAD(V, L, S0)                                   \
+  _Pragma("unroll") for (int k = 0; k < CG_PF; ++k) {           \
+    const int s_ = (S0) + k;                                    \
+    const bool ok_ = s_ < s1;                                   \
+    V[k] = ok_ ? sval[(size_t)s_ * 256 + tid] : 0.0;            \
+    L[k] = ok_ ? (int)slidx[(size_t)s_ * 256 + tid] : 0;        \
+  }
+#define NSX_CG_USE(V, L, S0)                                    \
+  _Pragma("unroll") for (int k = 0; k < CG_PF; ++k) {           \
+    const int s_ = (S0) + k;                                    \
+    if (s_ < s1) {                                              \
+      acc += V[k] * xst[L[k]];                                  \
+      const int inf = sinfo[s_];                                \
+      if (inf & 0x8000) {                                       \
+        const double r_ = cg_group_sum<16>(acc);                \
+        if (lane == 0) hvs[(inf & 0x7fff) * 16 + grp] = r_;     \
+        acc = 0.0;                                              \
+      }                                                         \
+    }                                                           \
+  }
+  NSX_CG_LOAD(va, la, s0)
+  for (int sb = s0; sb < s1; sb += 2 * CG_PF) {
+    NSX_CG_LOAD(vb, lb, sb + CG_PF)
+    NSX_CG_USE(va, la, sb)
+    NSX_CG_LOAD(va, la, sb + 2 * CG_PF)
+    NSX_CG_USE(vb, lb, sb + CG_PF)
+  }
+#undef NSX_CG_LOAD
+#undef NSX_CG_USE
+}
+
+__global__ __launch_bounds__(256) void k_cg_schur(int n_blocks, const int32_t *__restrict__ bptr, const int32_t *__restrict__ u_ptr,
+                                                  const int32_t *__restrict__ u_cols, const int32_t *__restrict__ s_ptr,
+                                                  const double *__restrict__ sval, const uint16_t *__restrict__ slidx,
+                                                  const int32_t *__restrict__ sinfo, const int64_t *__restrict__ dn_off,
+                                                  const double *__restrict__ P, const double *__restrict__ b, double *x, double *D0, double *D1,
+                                                  double *H, double rtol, int maxiter, unsigned long long *box, unsigned long long *box_other,
+                                                  double *pub_vals, unsigned long long *pub_flag, unsigned long long seq, int *err_dev) {
+  __shared__ double gs[CG_MAXB], hs[CG_MAXB], ds[CG_MAXB], hvs[CG_MAXB], xs[CG_MAXB], xst[CG_MAX_UCOLS];
   __shared__ double sh[2][4], bc[CG_NV];
   const int wg = blockIdx.x, tid = threadIdx.x, nwg = gridDim.x;
   // leave the other region empty for the next launch (stream order makes this visible to it)
   for (size_t q = (size_t)wg * 256 + tid; q < CG_REGION; q += (size_t)nwg * 256) box_other[q] = GX_EMPTY;
   const int r0 = bptr[wg], nb = bptr[wg + 1] - r0;
+  const int u0 = u_ptr[wg], nu = u_ptr[wg + 1] - u0;
+  const int s0 = s_ptr[wg], s1 = s_ptr[wg + 1];
   const double *Pb = P + dn_off[wg];
   const int grp = tid >> 4, lane = tid & 15;
   const bool own = tid < nb;
   int e = 0;
+  // the block's unique columns stay in registers for the whole solve (nu <= CG_MAX_UCOLS = 4 x 256)
+  int ucol[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) ucol[k] = tid + 256 * k < nu ? u_cols[u0 + tid + 256 * k] : -1;
+  gs[tid] = 0.0;  // rows beyond nb stay 0: the dense product reads gs[] unguarded
 
-  // h = P_b g on the block (16 lanes per row), result in hs[] and (write-through) in H
+  // h = P_b g on the block, 16 lanes per row, the loads of two rows in flight; result in hs[] and (write-through) in H
   auto apply_P = [&]() {
-    for (int q = grp; q < nb; q += 16) {
-      const double *prow = Pb + (size_t)q * nb;
-      double a0 = 0.0, a1 = 0.0;
-      int j = lane;
-      for (; j + 16 < nb; j += 32) {
-        a0 += prow[j] * gs[j];
-        a1 += prow[j + 16] * gs[j + 16];
+    double pa[16], pb[16];
+    auto fetch = [&](int q, double(&pv)[16]) {
+      const bool live = q < nb;
+      const double *prow = Pb + (size_t)(live ? q : 0) * nb;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const int j = lane + 16 * c;
+        pv[c] = (live && j < nb) ? prow[j] : 0.0;
       }
-      if (j < nb) a0 += prow[j] * gs[j];
-      const double acc = cg_group_sum<16>(a0 + a1);
+    };
+    auto use = [&](int q, const double(&pv)[16]) {
+      if (q >= nb) return;
+      double acc = 0.0;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) acc += pv[c] * gs[lane + 16 * c];
+      acc = cg_group_sum<16>(acc);
       if (lane == 0) hs[q] = acc;
+    };
+    fetch(grp, pa);
+    fetch(grp + 16, pb);
+    for (int q = grp; q < nb; q += 32) {
+      use(q, pa);
+      fetch(q + 32, pa);
+      use(q + 16, pb);
+      fetch(q + 48, pb);
     }
     __syncthreads();
     if (own) st_agent(H + r0 + tid, hs[tid]);
@@ -120,15 +194,13 @@ __global__ __launch_bounds__(256) void k_cg_schur(int n_blocks, const int32_t *_
     xs[tid] = x[r0 + tid];
     bi = b[r0 + tid];
   }
-  for (int q = grp; q < nb; q += 16) {
-    const int i = r0 + q;
-    double acc = 0.0;
-    for (int k = rp[i] + lane; k < rp[i + 1]; k += 16) acc += sv[k] * x[ci[k]];
-    acc = cg_group_sum<16>(acc);
-    if (lane == 0) gs[q] = acc;
-  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (ucol[k] >= 0) xst[tid + 256 * k] = x[ucol[k]];
   __syncthreads();
-  if (own) gs[tid] = gs[tid] - bi;
+  cg_block_spmv(s0, s1, sval, slidx, sinfo, xst, hvs, tid);
+  __syncthreads();
+  if (own) gs[tid] = hvs[tid] - bi;
   __syncthreads();
   apply_P();
   double tot3[3];
@@ -154,26 +226,20 @@ __global__ __launch_bounds__(256) void k_cg_schur(int n_blocks, const int32_t *_
     ++it;
     const double *Dp = (it & 1) ? D0 : D1;
     double *Dc = (it & 1) ? D1 : D0;
-    // ---- A: h = A d, d = -h(old) in the first iteration, beta d(old) - h(old) afterwards
-    for (int q = grp; q < nb; q += 16) {
-      const int i = r0 + q;
-      double acc = 0.0;
-      if (it == 1) {
-        for (int k = rp[i] + lane; k < rp[i + 1]; k += 16) acc += sv[k] * (-ld_agent(H + ci[k]));
-      } else {
-        for (int k = rp[i] + lane; k < rp[i + 1]; k += 16) {
-          const int j = ci[k];
-          acc += sv[k] * __builtin_fma(beta, ld_agent(Dp + j), -ld_agent(H + j));  // the owner's own expression, bit for bit
-        }
+    // ---- A: h = A d, d = -h(old) in the first iteration, beta d(old) - h(old) afterwards, evaluated for the block's columns
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (ucol[k] >= 0) {
+        const int j = ucol[k];
+        xst[tid + 256 * k] = it == 1 ? -ld_agent(H + j) : __builtin_fma(beta, ld_agent(Dp + j), -ld_agent(H + j));  // the owner's expression
       }
-      acc = cg_group_sum<16>(acc);
-      if (lane == 0) hvs[q] = acc;
-    }
     if (own) {
       const double dcur = it == 1 ? -hs[tid] : __builtin_fma(beta, ds[tid], -hs[tid]);  // d = beta d - h (SolverCG: d.sadd(beta, -1., h))
       ds[tid] = dcur;
       st_agent(Dc + r0 + tid, dcur);
     }
+    __syncthreads();
+    cg_block_spmv(s0, s1, sval, slidx, sinfo, xst, hvs, tid);
     __syncthreads();
     double tot1[1];
     {
@@ -216,6 +282,71 @@ __global__ __launch_bounds__(256) void k_cg_schur(int n_blocks, const int32_t *_
   }
 }
 
+// host: slab layout of negative_S_tilde per Schur ILU block (see above).  Built with the ILU schedules; values are
+// refreshed by cg_pack_values after every numeric Schur product.
+void build_cg_plan(nsx_handle *h) {
+  CgPlan &pl = h->cgplan;
+  pl.ok = false;
+  const IluSchedule &s = h->schedS;
+  if (h->dist || !s.dense || s.max_rows > CG_MAXB) return;
+  const Csr &g = h->gS.host;
+  const std::vector<int32_t> &bptr = s.block_ptr_h;
+  const int nb = s.n_blocks;
+  std::vector<int32_t> u_ptr(nb + 1, 0), u_cols, s_ptr(nb + 1, 0), s_info, s_src, tmp;
+  std::vector<uint16_t> s_lidx;
+  for (int b = 0; b < nb; ++b) {
+    const int r0 = bptr[b], r1 = bptr[b + 1], n = r1 - r0;
+    tmp.assign(g.colind.begin() + g.rowptr[r0], g.colind.begin() + g.rowptr[r1]);
+    std::sort(tmp.begin(), tmp.end());
+    tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+    if ((int)tmp.size() > CG_MAX_UCOLS) return;  // plan not applicable: the launch-per-operation solver stays in charge
+    u_cols.insert(u_cols.end(), tmp.begin(), tmp.end());
+    u_ptr[b + 1] = (int32_t)u_cols.size();
+    for (int r = 0; r * 16 < n; ++r) {
+      int maxlen = 0;
+      for (int q = 16 * r; q < std::min(n, 16 * r + 16); ++q) maxlen = std::max(maxlen, g.rowptr[r0 + q + 1] - g.rowptr[r0 + q]);
+      const int chunks = std::max(1, (maxlen + 15) / 16);
+      for (int c = 0; c < chunks; ++c) {
+        s_info.push_back(r | (c == chunks - 1 ? 0x8000 : 0));
+        for (int t = 0; t < 256; ++t) {
+          const int q = 16 * r + (t >> 4), e = 16 * c + (t & 15);
+          int32_t src = -1;
+          uint16_t li = 0;
+          if (q < n && g.rowptr[r0 + q] + e < g.rowptr[r0 + q + 1]) {
+            src = g.rowptr[r0 + q] + e;
+            li = (uint16_t)(std::lower_bound(tmp.begin(), tmp.end(), g.colind[src]) - tmp.begin());
+          }
+          s_src.push_back(src);
+          s_lidx.push_back(li);
+        }
+      }
+    }
+    s_ptr[b + 1] = (int32_t)s_info.size();
+  }
+  pl.n_slots = (int64_t)s_src.size();
+  pl.u_ptr.upload(u_ptr, h->stream);
+  pl.u_cols.upload(u_cols, h->stream);
+  pl.s_ptr.upload(s_ptr, h->stream);
+  pl.s_info.upload(s_info, h->stream);
+  pl.s_src.upload(s_src, h->stream);
+  pl.s_lidx.upload(s_lidx, h->stream);
+  pl.s_val.alloc((size_t)pl.n_slots);
+  pl.ok = true;
+  pl.values_current = false;
+  if (getenv("NSX_DEBUG"))
+    fprintf(stderr, "[nsx] persistent Schur CG plan: %d blocks, %lld slabs (fill %.2f), unique columns per block avg %.0f\n", nb,
+            (long long)s_info.size(), (double)g.nnz() / (double)std::max<int64_t>(1, pl.n_slots), (double)u_cols.size() / std::max(1, nb));
+}
+
+// after schur_numeric: the packed copy of the values
+void cg_pack_values(nsx_handle *h) {
+  CgPlan &pl = h->cgplan;
+  if (!pl.ok) return;
+  LaunchScope ls(h, "cg_pack", 20.0 * (double)pl.n_slots);
+  hipLaunchKernelGGL(k_cg_pack, dim3(cdiv(pl.n_slots, 256)), dim3(256), 0, h->stream, pl.n_slots, pl.s_src.p, h->vSchur.p, pl.s_val.p);
+  pl.values_current = true;
+}
+
 static void cg_setup(nsx_handle *h) {
   if (h->cg_box.p || h->cg_disabled) return;
   h->cg_max_wg = 0;
@@ -237,7 +368,8 @@ static void cg_setup(nsx_handle *h) {
 // operation path has to be used instead (distributed run, blocks too large or too many, persistent kernels disabled).
 bool cg_schur_persistent(nsx_handle *h, double *x, const double *b, double rtol, int maxiter, int *steps, double *last, int *status) {
   const IluSchedule &s = h->schedS;
-  if (h->comm || !s.dense || s.max_rows > CG_MAXB) return false;
+  const CgPlan &pl = h->cgplan;
+  if (h->comm || !s.dense || s.max_rows > CG_MAXB || !pl.ok || !pl.values_current) return false;
   cg_setup(h);
   if (h->cg_max_wg == 0 || s.n_blocks > h->cg_max_wg) return false;
   const int n = h->n_p;
@@ -252,8 +384,9 @@ bool cg_schur_persistent(nsx_handle *h, double *x, const double *b, double rtol,
   {
     LaunchScope ls(h, "cg_S", 0.0);
     pe = ls.e;
-    hipLaunchKernelGGL(k_cg_schur, dim3(s.n_blocks), dim3(256), 0, h->stream, s.n_blocks, s.block_ptr.p, h->gS.rowptr.p, h->gS.colind.p, h->vSchur.p,
-                       s.dn_off.p, s.dn_P.p, b, x, D0, D1, H, rtol, maxiter, box, box_other, pub_vals, pub_flag, seq, err_dev);
+    hipLaunchKernelGGL(k_cg_schur, dim3(s.n_blocks), dim3(256), 0, h->stream, s.n_blocks, s.block_ptr.p, pl.u_ptr.p, pl.u_cols.p, pl.s_ptr.p, pl.s_val.p,
+                       pl.s_lidx.p, pl.s_info.p, s.dn_off.p, s.dn_P.p, b, x, D0, D1, H, rtol, maxiter, box, box_other, pub_vals, pub_flag, seq,
+                       err_dev);
   }
   h->cg_parity ^= 1;
   wait_published(h, seq);
@@ -273,7 +406,7 @@ bool cg_schur_persistent(nsx_handle *h, double *x, const double *b, double rtol,
   *last = h->pub_host[S_CGP + 1];
   *status = st;
   // algorithmic bytes: per iteration the matrix (12 B / entry) and the block inverses once, plus the vectors
-  if (pe) pe->bytes += (double)(*steps + 1) * (12.0 * h->gS.nnz() + 8.0 * (double)s.dn_entries + 48.0 * n);
+  if (pe) pe->bytes += (double)(*steps + 1) * (10.0 * h->gS.nnz() + 8.0 * (double)s.dn_entries + 48.0 * n);
   return true;
 }
 

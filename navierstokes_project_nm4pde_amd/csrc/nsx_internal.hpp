@@ -150,6 +150,16 @@ struct SpmvBlocked {
   double ucols_total = 0;
 };
 
+// Persistent Schur-complement CG (nsx_cg.hip): negative_S_tilde as slabs of 256 slots per Schur ILU block, 16-bit columns
+// into the block's unique-column list.
+struct CgPlan {
+  bool ok = false, values_current = false;
+  int64_t n_slots = 0;
+  DevBuf<int32_t> u_ptr, u_cols, s_ptr, s_info, s_src;
+  DevBuf<uint16_t> s_lidx;
+  DevBuf<double> s_val;
+};
+
 struct ProfEntry {
   int64_t launches = 0;
   double bytes = 0;  // algorithmic bytes summed over the launches (a scope's size may vary: Gram-Schmidt sweeps)
@@ -219,9 +229,15 @@ struct nsx_handle {
   nsx::DevBuf<unsigned long long> mgs_box;
   bool sched_dirty = true;  // the ILU schedules do not match the current rank tables yet
   int mgs_used_wg[2] = {0, 0}, mgs_used_steps[2] = {0, 0};  // what the last launch on each region filled
-  int mgs_parity = 0, mgs_max_wg = 0;  // mgs_max_wg = 0: cooperative launch unavailable, the launch-per-step chain is used
+  int mgs_parity = 0, mgs_max_wg = 0;  // mgs_max_wg = 0: the launch-per-link chain is used
+  int mgs_max_wg20 = 0;                // the same limit for the 20-entries-per-thread instantiation
+  unsigned int mgs_commit_base = 0;    // workgroups that committed their part of w in all finished sweeps
+  int mgs_mode = 0;                    // exchange shape of the persistent sweep (nsx_blas.hip)
+  bool mgs_coop = false, mgs_disabled = false;
+  bool mgs_redo_ahead = false;         // a sweep fell back to the chain after work depending on its w had been enqueued
   // persistent Schur-complement CG (nsx_cg.hip: k_cg_schur): mailbox regions, work vectors (d double-buffered, h)
   nsx::DevBuf<unsigned long long> cg_box;
+  nsx::CgPlan cgplan;
   nsx::DevBuf<double> cg_vec;
   int cg_parity = 0, cg_max_wg = 0;
   bool cg_disabled = false;
@@ -346,6 +362,8 @@ unsigned long long publish_scalars(nsx_handle *h, int slot0, int count);  // asy
 void collect_published(nsx_handle *h, unsigned long long seq, int slot0, int count, double *out);
 void wait_published(nsx_handle *h, unsigned long long seq);  // host waits for the sequence number of a publication
 // persistent CG on the Schur complement (nsx_cg.hip); false: not applicable here, use the launch-per-operation solver
+void build_cg_plan(nsx_handle *h);   // with the ILU schedules
+void cg_pack_values(nsx_handle *h);  // after every schur_numeric
 bool cg_schur_persistent(nsx_handle *h, double *x, const double *b, double rtol, int maxiter, int *steps, double *last, int *status);
 void write_scalar(nsx_handle *h, int slot, double v);
 

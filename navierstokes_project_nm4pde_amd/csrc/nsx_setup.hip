@@ -451,6 +451,7 @@ void ensure_schedules(nsx_handle *h) {
   setup_ilu_schedule(h, h->gA.host, h->rank_u_h, h->schedF, lwF, bpwF, false, wideF && h->dim > 1);
   const bool denseS = !(getenv("NSX_DENSE_S") && atoi(getenv("NSX_DENSE_S")) == 0);
   setup_ilu_schedule(h, h->gS.host, h->sblk_h.empty() ? h->rank_p_h : h->sblk_h, h->schedS, lwS, bpwS, denseS);
+  build_cg_plan(h);
   h->sched_dirty = false;
 }
 

@@ -120,6 +120,10 @@ static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b,
         }
       };
       bool normalized = v_mgs(h, n, vv, dim, basis, S_H, !re_orth, hh, &next_A, consider);
+      if (h->mgs_redo_ahead) {  // the sweep fell back to the launch-per-link chain: A * vv was enqueued on an unfinished vv
+        h->mgs_redo_ahead = false;
+        ahead = false;
+      }
       double s = std::sqrt(hh[dim]);
       if (consider) {
         const double norm_vv_start = std::sqrt(hh[dim + 1]);  // |vv| before the sweep, computed inside it
@@ -247,6 +251,7 @@ void prec_initialize(nsx_handle *h, int type) {
   v_scale_vec(h, n_u, h->schur_w.p, h->dirmask.p);
   v_scale(h, n_u, h->schur_w.p, -1.0);
   schur_numeric(h, h->schur_w.p);
+  cg_pack_values(h);
   // preconditioner_F.initialize(*F); preconditioner_S.initialize(negative_S)   (Prec.hpp:147-148,250-251,361-362,470-471)
   ilu_factor(h, h->gA, h->schedF, h->vF.p, h->luF.p, "ilu_factor_F");
   ilu_factor(h, h->gS, h->schedS, h->vSchur.p, h->luS.p, "ilu_factor_S");
