@@ -213,11 +213,9 @@ void v_add_and_dot(nsx_handle *h, Span sp, double *d, double a, int aslot, const
 // reductions.  As separate launches every link streams w (read + write) and two basis vectors, 32 B per entry; here the
 // grid is co-resident, every thread keeps its entries of w and of the current v_i in registers for the whole sweep, and a
 // link costs ONE read of the next basis vector (8 B per entry, prefetched before the wait) plus a grid-wide exchange of
-// the partial sums (nsx_grid.hpp: mailboxes, no atomics on shared counters).  Two exchange shapes:
-//   MODE 0  workgroup 0 waits for all mailboxes, adds them in a fixed order and publishes the total, which every
-//           workgroup picks up (two hops through memory, 1 + nwg polled words per workgroup);
-//   MODE 1  every workgroup reads all mailboxes itself and adds them in the same fixed order (one hop, nwg polled words
-//           per workgroup; every workgroup computes bit-identical totals).
+// the partial sums (nsx_grid.hpp: mailboxes, no atomics on shared counters): workgroup 0 waits for all mailboxes, adds them
+// in a fixed order and publishes the total, which every workgroup picks up.  (Letting every workgroup read all mailboxes
+// itself — one hop instead of two — measured slower: 60 against 50 us per sweep, the polling traffic gets in its own way.)
 // The arithmetic of each entry is that of the chain (w += (-h) v_i), sums are fixed-order, so results do not depend on
 // timing.  Every wait is bounded by a wall-clock timeout: a grid that is not co-resident (another stream or process holds
 // compute units) ends without touching w, and the host falls back to the launch-per-link chain (v_mgs).
@@ -231,15 +229,17 @@ struct MgsArgs {
   const double *v[MGS_STEPS];
 };
 
-template <int E, int MODE>
+template <int E>
 __global__ __launch_bounds__(256) void k_mgs(int n, int split, int gap, double *__restrict__ w, MgsArgs V, int dim,
                                              unsigned long long *box, unsigned long long *box_next, int reset_wg, int reset_steps,
                                              double *__restrict__ scal_out, int *err_host, unsigned int *tail, int normalize, int consider,
                                              double *pub_vals, unsigned long long *pub_flag, unsigned long long seq) {
   __shared__ double sh[2][4];  // two buffers: a wave may start the next sum while a slower one still reads this one
   __shared__ unsigned long long bc;
+  __shared__ int s_err;  // raised by any thread whose wait timed out; read after the next barrier
   __shared__ double tots[MGS_STEPS];
   const int nwg = gridDim.x, wg = blockIdx.x, T = nwg * 256, t = wg * 256 + threadIdx.x;
+  if (threadIdx.x == 0) s_err = 0;
   unsigned long long *total = box + (size_t)MGS_STEPS * MGS_MAX_WG, *total_next = box_next + (size_t)MGS_STEPS * MGS_MAX_WG;
   // leave the other region empty for the next launch (stream order makes this visible to it): its last user filled
   // reset_steps rows of reset_wg mailboxes, possibly more than this grid has workgroups
@@ -274,33 +274,25 @@ __global__ __launch_bounds__(256) void k_mgs(int n, int split, int gap, double *
     const double part = gx_block_sum(acc, sh[0]);
     unsigned long long *row = box + (size_t)ri * MGS_MAX_WG;
     if (threadIdx.x == 0) gx_post(row + wg, part);
-    double hs;
-    if (MODE == 0) {
-      if (wg == 0) {
-        double a = 0.0;
-        for (int q = threadIdx.x; q < nwg; q += 256) a += gx_wait_value(row + q, &lerr);
-        const double tot = gx_block_sum(a, sh[1]);
-        // a total built on a timed-out mailbox must never go out: the others then time out as well and nobody writes w
-        const int bad = __syncthreads_or(lerr);
-        if (threadIdx.x == 0 && !bad) {
-          scal_out[ri] = tot;
-          gx_post(total + ri, tot);
-          tots[ri] = tot;
-        }
-      }
-      if (threadIdx.x == 0) bc = gx_wait(total + ri, &lerr);
-      dead = __syncthreads_or(lerr) != 0;
-      hs = __longlong_as_double((long long)bc);
-    } else {
+    if (wg == 0) {
       double a = 0.0;
       for (int q = threadIdx.x; q < nwg; q += 256) a += gx_wait_value(row + q, &lerr);
-      hs = gx_block_sum(a, sh[1]);
-      dead = __syncthreads_or(lerr) != 0;
-      if (wg == 0 && threadIdx.x == 0 && !dead) {
-        scal_out[ri] = hs;
-        tots[ri] = hs;
+      if (lerr) s_err = 1;
+      const double tot = gx_block_sum(a, sh[1]);
+      // a total built on a timed-out mailbox must never go out: the others then time out as well and nobody writes w
+      if (threadIdx.x == 0 && !s_err) {
+        scal_out[ri] = tot;
+        gx_post(total + ri, tot);
+        tots[ri] = tot;
       }
     }
+    if (threadIdx.x == 0) {
+      bc = gx_wait(total + ri, &lerr);
+      if (lerr) s_err = 1;
+    }
+    __syncthreads();
+    dead = s_err != 0;
+    const double hs = __longlong_as_double((long long)bc);
     if (dead) break;
     if (pre) {
       norm0_sq = hs;
@@ -361,8 +353,8 @@ static void mgs_setup(nsx_handle *h) {
   int cus = 0, per_cu = 0;
   HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->prm.device));
   int per_cu20 = 0;
-  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (k_mgs<10, 0>), 256, 0));
-  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu20, (k_mgs<20, 0>), 256, 0));
+  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mgs<10>, 256, 0));
+  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu20, k_mgs<20>, 256, 0));
   h->mgs_box.alloc(2 * MGS_REGION + MGS_TAIL);
   HIP_CHECK(hipMemsetAsync(h->mgs_box.p, 0xff, 2 * MGS_REGION * sizeof(unsigned long long), h->stream));
   HIP_CHECK(hipMemsetAsync(h->mgs_box.p + 2 * MGS_REGION, 0, MGS_TAIL * sizeof(unsigned long long), h->stream));
@@ -372,9 +364,8 @@ static void mgs_setup(nsx_handle *h) {
     h->mgs_max_wg = std::max(1, std::min(h->mgs_max_wg, atoi(getenv("NSX_MGS_MAXWG"))));
     h->mgs_max_wg20 = std::max(1, std::min(h->mgs_max_wg20, atoi(getenv("NSX_MGS_MAXWG"))));
   }
-  h->mgs_mode = getenv("NSX_MGS_MODE") ? atoi(getenv("NSX_MGS_MODE")) : 0;
   h->mgs_coop = getenv("NSX_MGS_COOP") && atoi(getenv("NSX_MGS_COOP")) != 0;
-  if (getenv("NSX_DEBUG")) fprintf(stderr, "[nsx] mgs sweep: %d CUs x %d resident workgroups, grid <= %d, exchange mode %d\n", cus, per_cu, h->mgs_max_wg, h->mgs_mode);
+  if (getenv("NSX_DEBUG")) fprintf(stderr, "[nsx] mgs sweep: %d CUs x %d resident workgroups, grid <= %d\n", cus, per_cu, h->mgs_max_wg);
 }
 
 void wait_published(nsx_handle *h, unsigned long long seq) {
@@ -453,8 +444,7 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
     // (/opt/skills/guides/MI355X_MICROARCH.md, "Residency and cooperative launch").  What makes the sweep safe is the bounded wait:
     // should a workgroup be missing (another stream or process holds compute units), the kernel ends without writing w and the
     // sweep is redone by the launch-per-link chain below.
-    const void *fn = per_thread <= 10 ? (h->mgs_mode == 1 ? (const void *)k_mgs<10, 1> : (const void *)k_mgs<10, 0>)
-                                      : (h->mgs_mode == 1 ? (const void *)k_mgs<20, 1> : (const void *)k_mgs<20, 0>);
+    const void *fn = per_thread <= 10 ? (const void *)k_mgs<10> : (const void *)k_mgs<20>;
     if (h->mgs_coop) HIP_CHECK(hipLaunchCooperativeKernel(fn, dim3(nwg), dim3(256), args, 0, h->stream));
     else HIP_CHECK(hipLaunchKernel(fn, dim3(nwg), dim3(256), args, 0, h->stream));
     h->mgs_used_wg[h->mgs_parity] = nwg;

@@ -20,6 +20,7 @@
 
 namespace nsx {
 
+constexpr int CG_THREADS = 512;  // two halves of 256: each streams the slabs of every other 16-row round of the block
 constexpr int CG_MAXB = 256;    // rows of one Schur block: one thread per row in the update phases
 constexpr int CG_MAX_WG = 1024;
 constexpr int CG_NV = 3;        // values per exchange
@@ -39,10 +40,19 @@ __device__ __forceinline__ double cg_group_sum(double v) {
   return v;
 }
 
-// grid-wide fixed-order sums of NV values; returns false when a wait timed out (the grid is then abandoned)
+// fixed-order sum over the 512 threads of the block, result in every thread (sh: 8 doubles, reusable after the next barrier)
+__device__ __forceinline__ double cg_block_sum(double v, double *sh) {
+  v = gx_wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return ((sh[0] + sh[1]) + (sh[2] + sh[3])) + ((sh[4] + sh[5]) + (sh[6] + sh[7]));
+}
+
+// grid-wide fixed-order sums of NV values; returns false when a wait timed out (the grid is then abandoned).
+// s_err: shared flag, raised by any thread whose wait timed out.
 template <int NV>
-__device__ __forceinline__ bool cg_exchange(const double (&part)[NV], double (&tot)[NV], unsigned long long *box, int e, int nwg, double (*sh)[4],
-                                            double *bc) {
+__device__ __forceinline__ bool cg_exchange(const double (&part)[NV], double (&tot)[NV], unsigned long long *box, int e, int nwg, double (*sh)[8],
+                                            double *bc, int *s_err) {
   // every data store of this workgroup (h, d: write-through) is acknowledged before its partial sums go out
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const int wg = blockIdx.x, tid = threadIdx.x;
@@ -51,7 +61,7 @@ __device__ __forceinline__ bool cg_exchange(const double (&part)[NV], double (&t
   unsigned long long *total2 = box + (size_t)CG_RING * CG_NV * CG_MAX_WG + (size_t)((e + 2) % CG_RING) * CG_NV;
   double bs[NV];
 #pragma unroll
-  for (int v = 0; v < NV; ++v) bs[v] = gx_block_sum(part[v], sh[v & 1]);
+  for (int v = 0; v < NV; ++v) bs[v] = cg_block_sum(part[v], sh[v & 1]);
   int lerr = 0;
   if (tid == 0) {
 #pragma unroll
@@ -60,23 +70,29 @@ __device__ __forceinline__ bool cg_exchange(const double (&part)[NV], double (&t
     for (int v = 0; v < CG_NV; ++v) gx_clear(row2 + (size_t)v * CG_MAX_WG + wg);
   }
   if (wg == 0) {
+    double a[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      double a = 0.0;
-      for (int s = tid; s < nwg; s += 256) a += gx_wait_value(row + (size_t)v * CG_MAX_WG + s, &lerr);
-      const double t = gx_block_sum(a, sh[(v + NV) & 1]);
-      if (tid == 0) gx_post(total + v, t);
+      a[v] = 0.0;
+      for (int q = tid; q < nwg; q += CG_THREADS) a[v] += gx_wait_value(row + (size_t)v * CG_MAX_WG + q, &lerr);
+    }
+    if (lerr) *s_err = 1;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const double t = cg_block_sum(a[v], sh[(v + NV) & 1]);
+      if (tid == 0 && !*s_err) gx_post(total + v, t);  // a total built on a timed-out mailbox never goes out
     }
     if (tid < CG_NV) gx_clear(total2 + tid);
   }
   if (tid == 0) {
 #pragma unroll
     for (int v = 0; v < NV; ++v) bc[v] = gx_wait_value(total + v, &lerr);
+    if (lerr) *s_err = 1;
   }
-  const int dead = __syncthreads_or(lerr);
+  __syncthreads();
 #pragma unroll
   for (int v = 0; v < NV; ++v) tot[v] = bc[v];
-  return dead == 0;
+  return *s_err == 0;
 }
 
 // ---- packed operator stream ------------------------------------------------------------------------------------------
@@ -95,7 +111,7 @@ __global__ void k_cg_pack(int64_t n_slots, const int32_t *__restrict__ src, cons
 
 // hv_q = sum_j S_qj xst[lidx]  for the rows of this block; 16 lanes per row, result in hvs[]
 __device__ __forceinline__ void cg_block_spmv(int s0, int s1, const double *__restrict__ sval, const uint16_t *__restrict__ slidx,
-                                              const int32_t *__restrict__ sinfo, const double *xst, double *hvs, int tid) {
+                                              const int32_t *__restrict__ sinfo, const double *xst, double *hvs, int tid /* 0..255 within the half */) {
   const int grp = tid >> 4, lane = tid & 15;
   double va[CG_PF], vb[CG_PF];
   int la[CG_PF], lb[CG_PF];
@@ -131,7 +147,7 @@ __device__ __forceinline__ void cg_block_spmv(int s0, int s1, const double *__re
 #undef NSX_CG_USE
 }
 
-__global__ __launch_bounds__(256) void k_cg_schur(int n_blocks, const int32_t *__restrict__ bptr, const int32_t *__restrict__ u_ptr,
+__global__ __launch_bounds__(CG_THREADS) void k_cg_schur(int n_blocks, const int32_t *__restrict__ bptr, const int32_t *__restrict__ u_ptr,
                                                   const int32_t *__restrict__ u_cols, const int32_t *__restrict__ s_ptr,
                                                   const double *__restrict__ sval, const uint16_t *__restrict__ slidx,
                                                   const int32_t *__restrict__ sinfo, const int64_t *__restrict__ dn_off,
@@ -139,22 +155,26 @@ __global__ __launch_bounds__(256) void k_cg_schur(int n_blocks, const int32_t *_
                                                   double *H, double rtol, int maxiter, unsigned long long *box, unsigned long long *box_other,
                                                   double *pub_vals, unsigned long long *pub_flag, unsigned long long seq, int *err_dev) {
   __shared__ double gs[CG_MAXB], hs[CG_MAXB], ds[CG_MAXB], hvs[CG_MAXB], xs[CG_MAXB], xst[CG_MAX_UCOLS];
-  __shared__ double sh[2][4], bc[CG_NV];
+  __shared__ double sh[2][8], bc[CG_NV];
+  __shared__ int s_err;
   const int wg = blockIdx.x, tid = threadIdx.x, nwg = gridDim.x;
+  if (tid == 0) s_err = 0;
   // leave the other region empty for the next launch (stream order makes this visible to it)
-  for (size_t q = (size_t)wg * 256 + tid; q < CG_REGION; q += (size_t)nwg * 256) box_other[q] = GX_EMPTY;
+  for (size_t q = (size_t)wg * CG_THREADS + tid; q < CG_REGION; q += (size_t)nwg * CG_THREADS) box_other[q] = GX_EMPTY;
   const int r0 = bptr[wg], nb = bptr[wg + 1] - r0;
   const int u0 = u_ptr[wg], nu = u_ptr[wg + 1] - u0;
-  const int s0 = s_ptr[wg], s1 = s_ptr[wg + 1];
+  // slabs of this block: the even 16-row rounds first (half 0 of the workgroup), then the odd ones (half 1)
+  const int half = tid >> 8, ht = tid & 255;
+  const int s0 = s_ptr[3 * wg + half], s1 = s_ptr[3 * wg + half + 1];
   const double *Pb = P + dn_off[wg];
-  const int grp = tid >> 4, lane = tid & 15;
+  const int grp = tid >> 4, lane = tid & 15;  // 32 row groups of 16 lanes in the dense product
   const bool own = tid < nb;
   int e = 0;
-  // the block's unique columns stay in registers for the whole solve (nu <= CG_MAX_UCOLS = 4 x 256)
-  int ucol[4];
+  // the block's unique columns stay in registers for the whole solve (nu <= CG_MAX_UCOLS = 2 x 512)
+  int ucol[2];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) ucol[k] = tid + 256 * k < nu ? u_cols[u0 + tid + 256 * k] : -1;
-  gs[tid] = 0.0;  // rows beyond nb stay 0: the dense product reads gs[] unguarded
+  for (int k = 0; k < 2; ++k) ucol[k] = tid + CG_THREADS * k < nu ? u_cols[u0 + tid + CG_THREADS * k] : -1;
+  if (tid < CG_MAXB) gs[tid] = 0.0;  // rows beyond nb stay 0: the dense product reads gs[] unguarded
 
   // h = P_b g on the block, 16 lanes per row, the loads of two rows in flight; result in hs[] and (write-through) in H
   auto apply_P = [&]() {
@@ -177,12 +197,12 @@ __global__ __launch_bounds__(256) void k_cg_schur(int n_blocks, const int32_t *_
       if (lane == 0) hs[q] = acc;
     };
     fetch(grp, pa);
-    fetch(grp + 16, pb);
-    for (int q = grp; q < nb; q += 32) {
+    fetch(grp + 32, pb);
+    for (int q = grp; q < nb; q += 64) {
       use(q, pa);
-      fetch(q + 32, pa);
-      use(q + 16, pb);
-      fetch(q + 48, pb);
+      fetch(q + 64, pa);
+      use(q + 32, pb);
+      fetch(q + 96, pb);
     }
     __syncthreads();
     if (own) st_agent(H + r0 + tid, hs[tid]);
@@ -195,10 +215,10 @@ __global__ __launch_bounds__(256) void k_cg_schur(int n_blocks, const int32_t *_
     bi = b[r0 + tid];
   }
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
-    if (ucol[k] >= 0) xst[tid + 256 * k] = x[ucol[k]];
+  for (int k = 0; k < 2; ++k)
+    if (ucol[k] >= 0) xst[tid + CG_THREADS * k] = x[ucol[k]];
   __syncthreads();
-  cg_block_spmv(s0, s1, sval, slidx, sinfo, xst, hvs, tid);
+  cg_block_spmv(s0, s1, sval, slidx, sinfo, xst, hvs, ht);
   __syncthreads();
   if (own) gs[tid] = hvs[tid] - bi;
   __syncthreads();
@@ -206,7 +226,7 @@ __global__ __launch_bounds__(256) void k_cg_schur(int n_blocks, const int32_t *_
   double tot3[3];
   {
     const double part[3] = {own ? gs[tid] * gs[tid] : 0.0, own ? bi * bi : 0.0, own ? gs[tid] * hs[tid] : 0.0};
-    if (!cg_exchange<3>(part, tot3, box, e++, nwg, sh, bc)) {
+    if (!cg_exchange<3>(part, tot3, box, e++, nwg, sh, bc, &s_err)) {
       if (tid == 0) __hip_atomic_store(err_dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (wg == 0 && tid == 0) {
         __hip_atomic_store(pub_vals + 2, 3.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -228,10 +248,10 @@ __global__ __launch_bounds__(256) void k_cg_schur(int n_blocks, const int32_t *_
     double *Dc = (it & 1) ? D1 : D0;
     // ---- A: h = A d, d = -h(old) in the first iteration, beta d(old) - h(old) afterwards, evaluated for the block's columns
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < 2; ++k)
       if (ucol[k] >= 0) {
         const int j = ucol[k];
-        xst[tid + 256 * k] = it == 1 ? -ld_agent(H + j) : __builtin_fma(beta, ld_agent(Dp + j), -ld_agent(H + j));  // the owner's expression
+        xst[tid + CG_THREADS * k] = it == 1 ? -ld_agent(H + j) : __builtin_fma(beta, ld_agent(Dp + j), -ld_agent(H + j));  // the owner's expression
       }
     if (own) {
       const double dcur = it == 1 ? -hs[tid] : __builtin_fma(beta, ds[tid], -hs[tid]);  // d = beta d - h (SolverCG: d.sadd(beta, -1., h))
@@ -239,12 +259,12 @@ __global__ __launch_bounds__(256) void k_cg_schur(int n_blocks, const int32_t *_
       st_agent(Dc + r0 + tid, dcur);
     }
     __syncthreads();
-    cg_block_spmv(s0, s1, sval, slidx, sinfo, xst, hvs, tid);
+    cg_block_spmv(s0, s1, sval, slidx, sinfo, xst, hvs, ht);
     __syncthreads();
     double tot1[1];
     {
       const double part[1] = {own ? ds[tid] * hvs[tid] : 0.0};
-      if (!cg_exchange<1>(part, tot1, box, e++, nwg, sh, bc)) {
+      if (!cg_exchange<1>(part, tot1, box, e++, nwg, sh, bc, &s_err)) {
         dead = true;
         break;
       }
@@ -260,7 +280,7 @@ __global__ __launch_bounds__(256) void k_cg_schur(int n_blocks, const int32_t *_
     double tot2[2];
     {
       const double part[2] = {own ? gs[tid] * gs[tid] : 0.0, own ? gs[tid] * hs[tid] : 0.0};
-      if (!cg_exchange<2>(part, tot2, box, e++, nwg, sh, bc)) {
+      if (!cg_exchange<2>(part, tot2, box, e++, nwg, sh, bc, &s_err)) {
         dead = true;
         break;
       }
@@ -292,7 +312,7 @@ void build_cg_plan(nsx_handle *h) {
   const Csr &g = h->gS.host;
   const std::vector<int32_t> &bptr = s.block_ptr_h;
   const int nb = s.n_blocks;
-  std::vector<int32_t> u_ptr(nb + 1, 0), u_cols, s_ptr(nb + 1, 0), s_info, s_src, tmp;
+  std::vector<int32_t> u_ptr(nb + 1, 0), u_cols, s_ptr(3 * (size_t)nb + 1, 0), s_info, s_src, tmp;
   std::vector<uint16_t> s_lidx;
   for (int b = 0; b < nb; ++b) {
     const int r0 = bptr[b], r1 = bptr[b + 1], n = r1 - r0;
@@ -302,26 +322,29 @@ void build_cg_plan(nsx_handle *h) {
     if ((int)tmp.size() > CG_MAX_UCOLS) return;  // plan not applicable: the launch-per-operation solver stays in charge
     u_cols.insert(u_cols.end(), tmp.begin(), tmp.end());
     u_ptr[b + 1] = (int32_t)u_cols.size();
-    for (int r = 0; r * 16 < n; ++r) {
-      int maxlen = 0;
-      for (int q = 16 * r; q < std::min(n, 16 * r + 16); ++q) maxlen = std::max(maxlen, g.rowptr[r0 + q + 1] - g.rowptr[r0 + q]);
-      const int chunks = std::max(1, (maxlen + 15) / 16);
-      for (int c = 0; c < chunks; ++c) {
-        s_info.push_back(r | (c == chunks - 1 ? 0x8000 : 0));
-        for (int t = 0; t < 256; ++t) {
-          const int q = 16 * r + (t >> 4), e = 16 * c + (t & 15);
-          int32_t src = -1;
-          uint16_t li = 0;
-          if (q < n && g.rowptr[r0 + q] + e < g.rowptr[r0 + q + 1]) {
-            src = g.rowptr[r0 + q] + e;
-            li = (uint16_t)(std::lower_bound(tmp.begin(), tmp.end(), g.colind[src]) - tmp.begin());
+    for (int half = 0; half < 2; ++half) {  // the even rounds (first half of the workgroup), then the odd ones
+      s_ptr[3 * (size_t)b + half] = (int32_t)s_info.size();
+      for (int r = half; r * 16 < n; r += 2) {
+        int maxlen = 0;
+        for (int q = 16 * r; q < std::min(n, 16 * r + 16); ++q) maxlen = std::max(maxlen, g.rowptr[r0 + q + 1] - g.rowptr[r0 + q]);
+        const int chunks = std::max(1, (maxlen + 15) / 16);
+        for (int c = 0; c < chunks; ++c) {
+          s_info.push_back(r | (c == chunks - 1 ? 0x8000 : 0));
+          for (int t = 0; t < 256; ++t) {
+            const int q = 16 * r + (t >> 4), e = 16 * c + (t & 15);
+            int32_t src = -1;
+            uint16_t li = 0;
+            if (q < n && g.rowptr[r0 + q] + e < g.rowptr[r0 + q + 1]) {
+              src = g.rowptr[r0 + q] + e;
+              li = (uint16_t)(std::lower_bound(tmp.begin(), tmp.end(), g.colind[src]) - tmp.begin());
+            }
+            s_src.push_back(src);
+            s_lidx.push_back(li);
           }
-          s_src.push_back(src);
-          s_lidx.push_back(li);
         }
       }
     }
-    s_ptr[b + 1] = (int32_t)s_info.size();
+    s_ptr[3 * (size_t)b + 2] = (int32_t)s_info.size();
   }
   pl.n_slots = (int64_t)s_src.size();
   pl.u_ptr.upload(u_ptr, h->stream);
@@ -356,7 +379,7 @@ static void cg_setup(nsx_handle *h) {
   }
   int cus = 0, per_cu = 0;
   HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->prm.device));
-  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_schur, 256, 0));
+  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_schur, CG_THREADS, 0));
   h->cg_box.alloc(2 * CG_REGION + 2);
   HIP_CHECK(hipMemsetAsync(h->cg_box.p, 0xff, 2 * CG_REGION * sizeof(unsigned long long), h->stream));
   HIP_CHECK(hipMemsetAsync(h->cg_box.p + 2 * CG_REGION, 0, 2 * sizeof(unsigned long long), h->stream));
@@ -384,7 +407,7 @@ bool cg_schur_persistent(nsx_handle *h, double *x, const double *b, double rtol,
   {
     LaunchScope ls(h, "cg_S", 0.0);
     pe = ls.e;
-    hipLaunchKernelGGL(k_cg_schur, dim3(s.n_blocks), dim3(256), 0, h->stream, s.n_blocks, s.block_ptr.p, pl.u_ptr.p, pl.u_cols.p, pl.s_ptr.p, pl.s_val.p,
+    hipLaunchKernelGGL(k_cg_schur, dim3(s.n_blocks), dim3(CG_THREADS), 0, h->stream, s.n_blocks, s.block_ptr.p, pl.u_ptr.p, pl.u_cols.p, pl.s_ptr.p, pl.s_val.p,
                        pl.s_lidx.p, pl.s_info.p, s.dn_off.p, s.dn_P.p, b, x, D0, D1, H, rtol, maxiter, box, box_other, pub_vals, pub_flag, seq,
                        err_dev);
   }

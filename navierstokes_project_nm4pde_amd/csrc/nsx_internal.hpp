@@ -232,7 +232,6 @@ struct nsx_handle {
   int mgs_parity = 0, mgs_max_wg = 0;  // mgs_max_wg = 0: the launch-per-link chain is used
   int mgs_max_wg20 = 0;                // the same limit for the 20-entries-per-thread instantiation
   unsigned int mgs_commit_base = 0;    // workgroups that committed their part of w in all finished sweeps
-  int mgs_mode = 0;                    // exchange shape of the persistent sweep (nsx_blas.hip)
   bool mgs_coop = false, mgs_disabled = false;
   bool mgs_redo_ahead = false;         // a sweep fell back to the chain after work depending on its w had been enqueued
   // persistent Schur-complement CG (nsx_cg.hip: k_cg_schur): mailbox regions, work vectors (d double-buffered, h)
