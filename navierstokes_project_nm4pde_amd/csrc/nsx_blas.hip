@@ -222,8 +222,9 @@ void v_add_and_dot(nsx_handle *h, Span sp, double *d, double a, int aslot, const
 constexpr int MGS_MAX_WG = 512;
 constexpr int MGS_STEPS = 32;     // >= max_n_tmp_vectors + 1
 constexpr size_t MGS_REGION = (size_t)MGS_STEPS * MGS_MAX_WG + MGS_STEPS;  // words per mailbox region (+ the totals)
-// after the two mailbox regions: [0] error raised by a workgroup that timed out, [1] number of workgroups that wrote w back
-constexpr size_t MGS_TAIL = 2;
+// after the two mailbox regions: one word per workgroup = sequence number of the last sweep whose part of w it wrote back
+// (distinct addresses: a shared counter would serialise 512 atomics at the end of every sweep)
+constexpr size_t MGS_TAIL = MGS_MAX_WG;
 
 struct MgsArgs {
   const double *v[MGS_STEPS];
@@ -232,7 +233,7 @@ struct MgsArgs {
 template <int E>
 __global__ __launch_bounds__(256) void k_mgs(int n, int split, int gap, double *__restrict__ w, MgsArgs V, int dim,
                                              unsigned long long *box, unsigned long long *box_next, int reset_wg, int reset_steps,
-                                             double *__restrict__ scal_out, int *err_host, unsigned int *tail, int normalize, int consider,
+                                             double *__restrict__ scal_out, int *err_host, unsigned long long *tail, int normalize, int consider,
                                              double *pub_vals, unsigned long long *pub_flag, unsigned long long seq) {
   __shared__ double sh[2][4];  // two buffers: a wave may start the next sum while a slower one still reads this one
   __shared__ unsigned long long bc;
@@ -320,7 +321,6 @@ __global__ __launch_bounds__(256) void k_mgs(int n, int split, int gap, double *
     // w stays as it was.  Tell the host (mapped word) and, from workgroup 0, wake it up
     if (threadIdx.x == 0) {
       __hip_atomic_store(err_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      __hip_atomic_store(tail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (wg == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(pub_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void k_mgs(int n, int split, int gap, double *
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(pub_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  if (threadIdx.x == 0) atomicAdd(tail + 1, 1u);  // this workgroup commits its part of w
+  if (threadIdx.x == 0) tail[wg] = seq;  // this workgroup commits its part of w
 #pragma unroll
   for (int k = 0; k < E; ++k)
     if (idx[k] >= 0) w[idx[k]] = wv[k];
@@ -384,18 +384,18 @@ void wait_published(nsx_handle *h, unsigned long long seq) {
 // A persistent sweep ended on a timeout (its grid was not co-resident).  Put the handle back into a usable state: wait for the
 // stragglers, empty the mailboxes, clear the error words and use the launch-per-link chain from now on.  Returns how many
 // workgroups had already written their part of w (0: w is untouched and the sweep can simply be redone by the chain).
-static unsigned int mgs_recover(nsx_handle *h) {
+static unsigned int mgs_recover(nsx_handle *h, unsigned long long failed_seq) {
   HIP_CHECK(hipStreamSynchronize(h->stream));
-  unsigned long long tail[MGS_TAIL] = {0, 0};
-  HIP_CHECK(hipMemcpy(tail, h->mgs_box.p + 2 * MGS_REGION, sizeof(tail), hipMemcpyDeviceToHost));
+  std::vector<unsigned long long> tail(MGS_TAIL, 0);
+  HIP_CHECK(hipMemcpy(tail.data(), h->mgs_box.p + 2 * MGS_REGION, MGS_TAIL * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   HIP_CHECK(hipMemsetAsync(h->mgs_box.p, 0xff, 2 * MGS_REGION * sizeof(unsigned long long), h->stream));
   HIP_CHECK(hipMemsetAsync(h->mgs_box.p + 2 * MGS_REGION, 0, MGS_TAIL * sizeof(unsigned long long), h->stream));
   *(volatile int *)(h->pub_host + N_SLOTS + 2) = 0;
   h->mgs_used_wg[0] = h->mgs_used_wg[1] = h->mgs_used_steps[0] = h->mgs_used_steps[1] = 0;
   h->mgs_max_wg = h->mgs_max_wg20 = 0;
   h->mgs_disabled = true;
-  const unsigned int committed = ((const unsigned int *)tail)[1] - h->mgs_commit_base;
-  h->mgs_commit_base = 0;
+  unsigned int committed = 0;
+  for (unsigned long long v : tail) committed += v == failed_seq;
   if (getenv("NSX_DEBUG")) fprintf(stderr, "[nsx] Gram-Schmidt sweep timed out (grid not co-resident): using one launch per link from now on\n");
   return committed;
 }
@@ -435,7 +435,7 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
     double *sout = h->scal.p + slot0, *pub_vals = h->pub_dev + slot0;
     unsigned long long *pub_flag = (unsigned long long *)(h->pub_dev + N_SLOTS), seq_ = seq;
     int *err = (int *)(h->pub_dev + N_SLOTS + 2);  // mapped host word
-    unsigned int *tail = (unsigned int *)(h->mgs_box.p + 2 * MGS_REGION);
+    unsigned long long *tail = h->mgs_box.p + 2 * MGS_REGION;
     int reset_wg = h->mgs_used_wg[1 - h->mgs_parity], reset_steps = h->mgs_used_steps[1 - h->mgs_parity];
     void *args[] = {&n_, &split, &gap, &w, &V, &dim_, &box, &box_next, &reset_wg, &reset_steps, &sout, &err, &tail, &norm_, &consider_, &pub_vals, &pub_flag, &seq_};
     // Co-residency: the grid never exceeds what the device holds at once (mgs_setup), the stream is in-order and normally nothing
@@ -459,7 +459,7 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
   if (ran_ahead) (*after_launch)();
   wait_published(h, seq);
   if (*(volatile int *)(h->pub_host + N_SLOTS + 2)) {
-    const unsigned int committed = mgs_recover(h);
+    const unsigned int committed = mgs_recover(h, seq);
     if (committed != 0) NSX_THROW(NSX_ERR_HIP, "Gram-Schmidt sweep: %u workgroups had written w when another one timed out", committed);
     // what after_launch enqueued (the next operator application) used the unfinished w: its result is a temporary that the
     // caller recomputes when told that w was not normalised here
@@ -467,7 +467,6 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
     if (ran_ahead) h->mgs_redo_ahead = true;
     return false;
   }
-  h->mgs_commit_base += (unsigned int)nwg;  // every workgroup of a finished sweep has committed its part of w
   for (int i = 0; i <= dim + (consider ? 1 : 0); ++i) out[i] = h->pub_host[slot0 + i];
   if (!normalize) return false;
   // the kernel's own decision, recomputed from the same two numbers

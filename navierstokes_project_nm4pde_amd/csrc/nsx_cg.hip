@@ -101,7 +101,7 @@ __device__ __forceinline__ bool cg_exchange(const double (&part)[NV], double (&t
 // entry 16c + lane of row 16r + grp for thread (grp, lane) — so every value load has an address that depends on the loop
 // counter alone and many slabs are in flight at once.  Columns are 16-bit indices into the block's list of unique columns,
 // whose d entries are staged in LDS once per iteration (~400 gathers per block instead of ~7000).
-constexpr int CG_PF = 8;         // slabs per register set (two sets in flight)
+constexpr int CG_PF = 4;         // slabs per register set (two sets in flight; 16 waves per CU keep ~64 KB in flight)
 constexpr int CG_MAX_UCOLS = 1024;
 
 __global__ void k_cg_pack(int64_t n_slots, const int32_t *__restrict__ src, const double *__restrict__ sv, double *__restrict__ out) {
@@ -147,7 +147,8 @@ __device__ __forceinline__ void cg_block_spmv(int s0, int s1, const double *__re
 #undef NSX_CG_USE
 }
 
-__global__ __launch_bounds__(CG_THREADS) void k_cg_schur(int n_blocks, const int32_t *__restrict__ bptr, const int32_t *__restrict__ u_ptr,
+// two workgroups (one Schur block each) per compute unit: 16 waves per CU, <= 128 registers per thread
+__global__ __launch_bounds__(CG_THREADS, 4) void k_cg_schur(int n_blocks, const int32_t *__restrict__ bptr, const int32_t *__restrict__ u_ptr,
                                                   const int32_t *__restrict__ u_cols, const int32_t *__restrict__ s_ptr,
                                                   const double *__restrict__ sval, const uint16_t *__restrict__ slidx,
                                                   const int32_t *__restrict__ sinfo, const int64_t *__restrict__ dn_off,
@@ -176,33 +177,51 @@ __global__ __launch_bounds__(CG_THREADS) void k_cg_schur(int n_blocks, const int
   for (int k = 0; k < 2; ++k) ucol[k] = tid + CG_THREADS * k < nu ? u_cols[u0 + tid + CG_THREADS * k] : -1;
   if (tid < CG_MAXB) gs[tid] = 0.0;  // rows beyond nb stay 0: the dense product reads gs[] unguarded
 
-  // h = P_b g on the block, 16 lanes per row, the loads of two rows in flight; result in hs[] and (write-through) in H
+  // h = P_b g on the block, 16 lanes per row (32 rows at a time); result in hs[] and (write-through) in H.  Blocks of up to
+  // 128 rows (the usual case) keep the loads of two rows in flight; larger ones use one register set of twice the width.
   auto apply_P = [&]() {
-    double pa[16], pb[16];
-    auto fetch = [&](int q, double(&pv)[16]) {
-      const bool live = q < nb;
-      const double *prow = Pb + (size_t)(live ? q : 0) * nb;
+    if (nb <= 128) {
+      double pa[8], pb[8];
+      auto fetch = [&](int q, double(&pv)[8]) {
+        const bool live = q < nb;
+        const double *prow = Pb + (size_t)(live ? q : 0) * nb;
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        const int j = lane + 16 * c;
-        pv[c] = (live && j < nb) ? prow[j] : 0.0;
+        for (int c = 0; c < 8; ++c) {
+          const int j = lane + 16 * c;
+          pv[c] = (live && j < nb) ? prow[j] : 0.0;
+        }
+      };
+      auto use = [&](int q, const double(&pv)[8]) {
+        if (q >= nb) return;
+        double acc = 0.0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc += pv[c] * gs[lane + 16 * c];
+        acc = cg_group_sum<16>(acc);
+        if (lane == 0) hs[q] = acc;
+      };
+      fetch(grp, pa);
+      fetch(grp + 32, pb);
+      for (int q = grp; q < nb; q += 64) {
+        use(q, pa);
+        fetch(q + 64, pa);
+        use(q + 32, pb);
+        fetch(q + 96, pb);
       }
-    };
-    auto use = [&](int q, const double(&pv)[16]) {
-      if (q >= nb) return;
-      double acc = 0.0;
+    } else {
+      for (int q = grp; q < nb; q += 32) {
+        const double *prow = Pb + (size_t)q * nb;
+        double pv[16];
 #pragma unroll
-      for (int c = 0; c < 16; ++c) acc += pv[c] * gs[lane + 16 * c];
-      acc = cg_group_sum<16>(acc);
-      if (lane == 0) hs[q] = acc;
-    };
-    fetch(grp, pa);
-    fetch(grp + 32, pb);
-    for (int q = grp; q < nb; q += 64) {
-      use(q, pa);
-      fetch(q + 64, pa);
-      use(q + 32, pb);
-      fetch(q + 96, pb);
+        for (int c = 0; c < 16; ++c) {
+          const int j = lane + 16 * c;
+          pv[c] = j < nb ? prow[j] : 0.0;
+        }
+        double acc = 0.0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc += pv[c] * gs[lane + 16 * c];
+        acc = cg_group_sum<16>(acc);
+        if (lane == 0) hs[q] = acc;
+      }
     }
     __syncthreads();
     if (own) st_agent(H + r0 + tid, hs[tid]);

@@ -231,7 +231,6 @@ struct nsx_handle {
   int mgs_used_wg[2] = {0, 0}, mgs_used_steps[2] = {0, 0};  // what the last launch on each region filled
   int mgs_parity = 0, mgs_max_wg = 0;  // mgs_max_wg = 0: the launch-per-link chain is used
   int mgs_max_wg20 = 0;                // the same limit for the 20-entries-per-thread instantiation
-  unsigned int mgs_commit_base = 0;    // workgroups that committed their part of w in all finished sweeps
   bool mgs_coop = false, mgs_disabled = false;
   bool mgs_redo_ahead = false;         // a sweep fell back to the chain after work depending on its w had been enqueued
   // persistent Schur-complement CG (nsx_cg.hip: k_cg_schur): mailbox regions, work vectors (d double-buffered, h)

@@ -63,8 +63,9 @@ class NavierStokes {
 public:
   // mesh_file_name: a gmsh .msh file, or "level:N" for the built-in cylinder generator (no .msh ships with the reference)
   NavierStokes(const std::string &mesh_file_name_, const unsigned int &degree_velocity_, const unsigned int &degree_pressure_,
-               const double &T_, const double &deltat_, const int test_case_ = 2, const int n_ranks_ = 1)
-      : test_case(test_case_), inlet_velocity(test_case_), T(T_), mesh_file_name(mesh_file_name_), degree_velocity(degree_velocity_),
+               const double &T_, const double &deltat_, const int test_case_ = 2, const int n_ranks_ = 1,
+               const double u_m_ = dim == 3 ? 9.0 : 1.5)  // u_m: a hard-coded member in the reference (NavierStokes3D.hpp:80: Re = 400); 2.25 gives Re = 100
+      : test_case(test_case_), inlet_velocity(test_case_, u_m_), T(T_), mesh_file_name(mesh_file_name_), degree_velocity(degree_velocity_),
         degree_pressure(degree_pressure_), deltat(deltat_), n_ranks(n_ranks_) {
     if (degree_velocity != 2 || degree_pressure != 1) throw std::runtime_error("only Taylor-Hood P2/P1 is supported");
   }

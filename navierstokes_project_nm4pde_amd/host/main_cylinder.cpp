@@ -1,6 +1,6 @@
 // main_cylinder.cpp — the reference's navier_stokes3D / navier_stokes2D executables on the C++ host mirror
 // (reference Navier-Stokes/src/main3D.cpp:4-79, src/main2D.cpp:4-63).  Compiled twice: -DNSX_DIM=3 / -DNSX_DIM=2.
-//   usage: navier_stokes{2,3}D [mesh.msh | level:N] [n_steps] [n_ranks] [write_output 0|1]
+//   usage: navier_stokes{2,3}D [mesh.msh | level:N] [n_steps] [n_ranks] [write_output 0|1] [u_m]
 #include <chrono>
 
 #include "NavierStokes.hpp"
@@ -18,7 +18,8 @@ int main(int argc, char *argv[]) {
   const int n_ranks = argc > 3 ? std::atoi(argv[3]) : 1;
   try {
     const auto t0 = std::chrono::steady_clock::now();
-    nsx::NavierStokes<NSX_DIM> problem(mesh_file_name, degree_velocity, degree_pressure, T, deltat, 2, n_ranks);
+    const double u_m = argc > 5 ? std::atof(argv[5]) : (NSX_DIM == 3 ? 9.0 : 1.5);  // NavierStokes3D.hpp:80 / NavierStokes2D.hpp:80; 2.25: Re = 100 in 3D
+    nsx::NavierStokes<NSX_DIM> problem(mesh_file_name, degree_velocity, degree_pressure, T, deltat, 2, n_ranks, u_m);
     if (argc > 4) problem.write_output = problem.write_csv = std::atoi(argv[4]) != 0;
     problem.setup();
     problem.solve();

@@ -1,0 +1,69 @@
+"""include/nsx_dealii_adaptor.hpp cannot be compiled here (no deal.II / Trilinos).  What can be checked
+without them: every libnsx call it makes exists in include/nsx.h with the number of arguments used, every entry point a
+drop-in needs is actually used, and the file cites the reference members it replaces."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _strip_comments(src):
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    return re.sub(r"//[^\n]*", " ", src)
+
+
+def _calls(src, pattern):
+    """(name, n_args) of every `name(...)` whose name matches pattern; arguments counted at parenthesis depth 0."""
+    out = []
+    for m in re.finditer(pattern + r"\s*\(", src):
+        name = m.group(0)[:m.group(0).index("(")].strip()
+        i, depth, commas, empty = m.end(), 1, 0, True
+        while depth:
+            ch = src[i]
+            if ch in "([{":
+                depth += 1
+            elif ch in ")]}":
+                depth -= 1
+            elif ch == "," and depth == 1:
+                commas += 1
+            if depth and not ch.isspace():
+                empty = False
+            i += 1
+        out.append((name, 0 if empty else commas + 1))
+    return out
+
+
+def test_adaptor_calls_match_the_c_abi():
+    hdr = _strip_comments(open(os.path.join(ROOT, "include", "nsx.h")).read())
+    ada = _strip_comments(open(os.path.join(ROOT, "include", "nsx_dealii_adaptor.hpp")).read())
+    decl = {}
+    for name, n in _calls(hdr, r"\bnsx_[a-z_]+"):
+        if name.endswith("_fn"):
+            continue
+        decl[name] = 1 if name in ("nsx_version",) and n == 1 else n  # `(void)` counts as one token
+    decl["nsx_version"] = 0
+    used = [(n, k) for n, k in _calls(ada, r"\bnsx_[a-z_]+") if n in decl or n.startswith("nsx_")]
+    used = [(n, k) for n, k in used if n not in ("nsx_params", "nsx_solve_stats", "nsx_handle")]
+    assert used, "the adaptor calls nothing?"
+    for name, n in used:
+        assert name in decl, "%s is not declared in include/nsx.h" % name
+        assert decl[name] == n, "%s called with %d arguments, declared with %d" % (name, n, decl[name])
+    needed = {"nsx_create", "nsx_destroy", "nsx_set_tables", "nsx_set_mesh", "nsx_set_mesh_distributed", "nsx_comm_init_callbacks",
+              "nsx_set_ranks", "nsx_assemble", "nsx_assemble_time_step", "nsx_apply_boundary_values", "nsx_solve_time_step",
+              "nsx_prec_initialize", "nsx_prec_vmult", "nsx_export_block", "nsx_set_solution", "nsx_get_solution"}
+    assert needed <= {n for n, _ in used}, needed - {n for n, _ in used}
+
+
+def test_adaptor_cites_the_members_it_replaces_and_says_it_is_not_compiled_here():
+    raw = open(os.path.join(ROOT, "include", "nsx_dealii_adaptor.hpp")).read()
+    assert "NOT COMPILED IN THIS REPOSITORY" in raw
+    for cite in ("NavierStokes3D.hpp:126-127", "NavierStokes3D.cpp:163-356", "NavierStokes3D.cpp:361-544", "NavierStokes3D.cpp:546-640",
+                 "Preconditioners.hpp:122-126", "336-340", "431-435"):
+        assert cite in raw, cite
+    for cls in ("PreconditionSIMPLENsx", "PreconditionaSIMPLENsx", "PreconditionYosidaNsx", "PreconditionaYosidaNsx"):
+        assert "class " + cls in raw
+    # the reference files the citations point at exist where this container has the reference (not on the GPU box)
+    ref = "/root/reference/Navier-Stokes"
+    if os.path.isdir(ref):
+        for rel in ("include/NavierStokes3D.hpp", "src/NavierStokes3D.cpp", "include/Preconditioners.hpp"):
+            assert os.path.exists(os.path.join(ref, rel))

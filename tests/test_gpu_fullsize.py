@@ -54,7 +54,8 @@ def test_full_size_operator_identities_and_solve(big):
     p[d.n_u:] = rng.standard_normal(d.n_p)
     Av, Ap = dev.system_vmult(v), dev.system_vmult(p)
     assert abs(Ap[:d.n_u] @ v[:d.n_u] + Av[d.n_u:] @ p[d.n_u:]) < 1e-10 * abs(Av[d.n_u:] @ p[d.n_u:])
-    # one time step at the reference's tolerances: Dirichlet values reproduced, true residual small, ILU(0) blocks sane
+    # one time step at the reference's tolerances: Dirichlet values reproduced, true residual small (the ILU(0) factors
+    # and triangular solves are checked entry by entry in the next test)
     bd, bv = cylinder_boundary_values(d, InletVelocity(3), dt)
     dev.apply_boundary_values(bd, bv)
     b = dev.rhs
@@ -65,9 +66,6 @@ def test_full_size_operator_identities_and_solve(big):
     assert np.linalg.norm(r) < 2e-2 * np.linalg.norm(b)                    # stopping test is on the preconditioned residual (1e-4 abs)
     assert np.abs(x[bd] - bv).max() < 1e-5 * max(1.0, np.abs(bv).max())
     assert np.array_equal(dev.solution, x)                                 # solution = solution_owned
-    # ILU(0) property on the factor pattern: (L D U)_ii reproduces F_ii; checked through z = ILU^{-1}(F e_block) ~ e
-    z = dev.ilu_apply(0, dev.system_vmult(e)[:d.n_u] * 0 + y[:d.n_u])
-    assert np.isfinite(z).all()
 
 
 def test_full_size_ilu_factors_and_triangular_solves(big):
