@@ -20,7 +20,8 @@
 
 namespace nsx {
 
-constexpr int CG_THREADS = 512;  // two halves of 256: each streams the slabs of every other 16-row round of the block
+constexpr int CG_THREADS = 256;  // 256 or 512 (two halves of 256: each streams the slabs of every other 16-row round of the block)
+constexpr int CG_NW = CG_THREADS / 64, CG_NG = CG_THREADS / 16;  // waves, 16-lane row groups
 constexpr int CG_MAXB = 256;    // rows of one Schur block: one thread per row in the update phases
 constexpr int CG_MAX_WG = 1024;
 constexpr int CG_NV = 3;        // values per exchange
@@ -40,59 +41,94 @@ __device__ __forceinline__ double cg_group_sum(double v) {
   return v;
 }
 
-// fixed-order sum over the 512 threads of the block, result in every thread (sh: 8 doubles, reusable after the next barrier)
-__device__ __forceinline__ double cg_block_sum(double v, double *sh) {
-  v = gx_wave_sum(v);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-  __syncthreads();
-  return ((sh[0] + sh[1]) + (sh[2] + sh[3])) + ((sh[4] + sh[5]) + (sh[6] + sh[7]));
+// Grid-wide fixed-order sums of NV values in two halves, so that the caller can issue loads between them:
+//   cg_post:     the workgroup's partial sums go out (one barrier for all NV values); workgroup 0 also waits for every
+//                mailbox and publishes the totals
+//   cg_collect:  wait for the totals.  Returns false when a wait timed out (the grid is then abandoned).
+// sh: [4][CG_NV * 8] doubles (two stages x exchange parity), s_err: shared flag raised by any thread whose wait timed out.
+struct CgBox {
+  unsigned long long *row, *row2, *total, *total2;
+};
+__device__ __forceinline__ CgBox cg_box_of(unsigned long long *box, int e) {
+  CgBox b;
+  b.row = box + (size_t)(e % CG_RING) * CG_NV * CG_MAX_WG;
+  b.row2 = box + (size_t)((e + 2) % CG_RING) * CG_NV * CG_MAX_WG;
+  b.total = box + (size_t)CG_RING * CG_NV * CG_MAX_WG + (size_t)(e % CG_RING) * CG_NV;
+  b.total2 = box + (size_t)CG_RING * CG_NV * CG_MAX_WG + (size_t)((e + 2) % CG_RING) * CG_NV;
+  return b;
+}
+__device__ __forceinline__ double cg_sum8(const double *w) {  // the per-wave sums of the block in a fixed order
+  if (CG_NW == 4) return (w[0] + w[1]) + (w[2] + w[3]);
+  return ((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]));
 }
 
-// grid-wide fixed-order sums of NV values; returns false when a wait timed out (the grid is then abandoned).
-// s_err: shared flag, raised by any thread whose wait timed out.
 template <int NV>
-__device__ __forceinline__ bool cg_exchange(const double (&part)[NV], double (&tot)[NV], unsigned long long *box, int e, int nwg, double (*sh)[8],
-                                            double *bc, int *s_err) {
-  // every data store of this workgroup (h, d: write-through) is acknowledged before its partial sums go out
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  const int wg = blockIdx.x, tid = threadIdx.x;
-  unsigned long long *row = box + (size_t)(e % CG_RING) * CG_NV * CG_MAX_WG, *row2 = box + (size_t)((e + 2) % CG_RING) * CG_NV * CG_MAX_WG;
-  unsigned long long *total = box + (size_t)CG_RING * CG_NV * CG_MAX_WG + (size_t)(e % CG_RING) * CG_NV;
-  unsigned long long *total2 = box + (size_t)CG_RING * CG_NV * CG_MAX_WG + (size_t)((e + 2) % CG_RING) * CG_NV;
-  double bs[NV];
+__device__ __forceinline__ void cg_post(const double (&part)[NV], unsigned long long *box, int e, int nwg, double (*sh)[CG_NV * 8], int *s_err) {
+  const int wg = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
+  const CgBox bx = cg_box_of(box, e);
+  double *buf = sh[2 * (e & 1)], *buf0 = sh[2 * (e & 1) + 1];
+  double ws[NV];
 #pragma unroll
-  for (int v = 0; v < NV; ++v) bs[v] = cg_block_sum(part[v], sh[v & 1]);
-  int lerr = 0;
+  for (int v = 0; v < NV; ++v) ws[v] = gx_wave_sum(part[v]);
+  // every data store of this wave (h, d: write-through) is acknowledged before the barrier behind which the sums go out
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if ((tid & 63) == 0) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) buf[v * 8 + wave] = ws[v];
+  }
+  __syncthreads();
   if (tid == 0) {
 #pragma unroll
-    for (int v = 0; v < NV; ++v) gx_post(row + (size_t)v * CG_MAX_WG + wg, bs[v]);
+    for (int v = 0; v < NV; ++v) gx_post(bx.row + (size_t)v * CG_MAX_WG + wg, cg_sum8(buf + v * 8));
 #pragma unroll
-    for (int v = 0; v < CG_NV; ++v) gx_clear(row2 + (size_t)v * CG_MAX_WG + wg);
+    for (int v = 0; v < CG_NV; ++v) gx_clear(bx.row2 + (size_t)v * CG_MAX_WG + wg);
   }
   if (wg == 0) {
+    int lerr = 0;
     double a[NV];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      a[v] = 0.0;
-      for (int q = tid; q < nwg; q += CG_THREADS) a[v] += gx_wait_value(row + (size_t)v * CG_MAX_WG + q, &lerr);
+    for (int v = 0; v < NV; ++v) a[v] = 0.0;
+    for (int q = tid; q < nwg; q += CG_THREADS) {
+      double m[NV];
+      gx_wait_n<NV>(bx.row + q, CG_MAX_WG, m, &lerr);  // the NV words of mailbox q polled together
+#pragma unroll
+      for (int v = 0; v < NV; ++v) a[v] += m[v];
     }
     if (lerr) *s_err = 1;
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      const double t = cg_block_sum(a[v], sh[(v + NV) & 1]);
-      if (tid == 0 && !*s_err) gx_post(total + v, t);  // a total built on a timed-out mailbox never goes out
-    }
-    if (tid < CG_NV) gx_clear(total2 + tid);
-  }
-  if (tid == 0) {
+    for (int v = 0; v < NV; ++v) ws[v] = gx_wave_sum(a[v]);
+    if ((tid & 63) == 0) {
 #pragma unroll
-    for (int v = 0; v < NV; ++v) bc[v] = gx_wait_value(total + v, &lerr);
+      for (int v = 0; v < NV; ++v) buf0[v * 8 + wave] = ws[v];
+    }
+    __syncthreads();
+    if (tid == 0 && !*s_err) {  // a total built on a timed-out mailbox never goes out
+#pragma unroll
+      for (int v = 0; v < NV; ++v) gx_post(bx.total + v, cg_sum8(buf0 + v * 8));
+    }
+    if (tid < CG_NV) gx_clear(bx.total2 + tid);
+  }
+}
+template <int NV>
+__device__ __forceinline__ bool cg_collect(double (&tot)[NV], unsigned long long *box, int e, double *bc, int *s_err) {
+  if (threadIdx.x == 0) {
+    int lerr = 0;
+    double m[NV];
+    gx_wait_n<NV>(cg_box_of(box, e).total, 1, m, &lerr);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) bc[v] = m[v];
     if (lerr) *s_err = 1;
   }
   __syncthreads();
 #pragma unroll
   for (int v = 0; v < NV; ++v) tot[v] = bc[v];
   return *s_err == 0;
+}
+template <int NV>
+__device__ __forceinline__ bool cg_exchange(const double (&part)[NV], double (&tot)[NV], unsigned long long *box, int e, int nwg, double (*sh)[CG_NV * 8],
+                                            double *bc, int *s_err) {
+  cg_post<NV>(part, box, e, nwg, sh, s_err);
+  return cg_collect<NV>(tot, box, e, bc, s_err);
 }
 
 // ---- packed operator stream ------------------------------------------------------------------------------------------
@@ -101,7 +137,7 @@ __device__ __forceinline__ bool cg_exchange(const double (&part)[NV], double (&t
 // entry 16c + lane of row 16r + grp for thread (grp, lane) — so every value load has an address that depends on the loop
 // counter alone and many slabs are in flight at once.  Columns are 16-bit indices into the block's list of unique columns,
 // whose d entries are staged in LDS once per iteration (~400 gathers per block instead of ~7000).
-constexpr int CG_PF = 4;         // slabs per register set (two sets in flight; 16 waves per CU keep ~64 KB in flight)
+constexpr int CG_PF = 8;         // slabs per register set (two sets in flight)
 constexpr int CG_MAX_UCOLS = 1024;
 
 __global__ void k_cg_pack(int64_t n_slots, const int32_t *__restrict__ src, const double *__restrict__ sv, double *__restrict__ out) {
@@ -109,13 +145,8 @@ __global__ void k_cg_pack(int64_t n_slots, const int32_t *__restrict__ src, cons
   if (i < n_slots) out[i] = src[i] >= 0 ? sv[src[i]] : 0.0;
 }
 
-// hv_q = sum_j S_qj xst[lidx]  for the rows of this block; 16 lanes per row, result in hvs[]
-__device__ __forceinline__ void cg_block_spmv(int s0, int s1, const double *__restrict__ sval, const uint16_t *__restrict__ slidx,
-                                              const int32_t *__restrict__ sinfo, const double *xst, double *hvs, int tid /* 0..255 within the half */) {
-  const int grp = tid >> 4, lane = tid & 15;
-  double va[CG_PF], vb[CG_PF];
-  int la[CG_PF], lb[CG_PF];
-  double acc = 0.0;
+// hv_q = sum_j S_qj xst[lidx]  for the rows of this block; 16 lanes per row, result in hvs[].  The first register set is
+// loaded by cg_spmv_prefetch, which the caller issues early (the values do not depend on the exchange in front of the product).
 #define NSX_CG_LOAD(V, L, S0)                                   \
   _Pragma("unroll") for (int k = 0; k < CG_PF; ++k) {           \
     const int s_ = (S0) + k;                                    \
@@ -123,6 +154,17 @@ __device__ __forceinline__ void cg_block_spmv(int s0, int s1, const double *__re
     V[k] = ok_ ? sval[(size_t)s_ * 256 + tid] : 0.0;            \
     L[k] = ok_ ? (int)slidx[(size_t)s_ * 256 + tid] : 0;        \
   }
+__device__ __forceinline__ void cg_spmv_prefetch(int s0, int s1, const double *__restrict__ sval, const uint16_t *__restrict__ slidx, int tid,
+                                                 double (&va)[CG_PF], int (&la)[CG_PF]) {
+  NSX_CG_LOAD(va, la, s0)
+}
+__device__ __forceinline__ void cg_block_spmv(int s0, int s1, const double *__restrict__ sval, const uint16_t *__restrict__ slidx,
+                                              const int32_t *__restrict__ sinfo, const double *xst, double *hvs, int tid /* 0..255 within the half */,
+                                              double (&va)[CG_PF], int (&la)[CG_PF]) {
+  const int grp = tid >> 4, lane = tid & 15;
+  double vb[CG_PF];
+  int lb[CG_PF];
+  double acc = 0.0;
 #define NSX_CG_USE(V, L, S0)                                    \
   _Pragma("unroll") for (int k = 0; k < CG_PF; ++k) {           \
     const int s_ = (S0) + k;                                    \
@@ -136,19 +178,17 @@ __device__ __forceinline__ void cg_block_spmv(int s0, int s1, const double *__re
       }                                                         \
     }                                                           \
   }
-  NSX_CG_LOAD(va, la, s0)
   for (int sb = s0; sb < s1; sb += 2 * CG_PF) {
     NSX_CG_LOAD(vb, lb, sb + CG_PF)
     NSX_CG_USE(va, la, sb)
     NSX_CG_LOAD(va, la, sb + 2 * CG_PF)
     NSX_CG_USE(vb, lb, sb + CG_PF)
   }
-#undef NSX_CG_LOAD
 #undef NSX_CG_USE
 }
+#undef NSX_CG_LOAD
 
-// two workgroups (one Schur block each) per compute unit: 16 waves per CU, <= 128 registers per thread
-__global__ __launch_bounds__(CG_THREADS, 4) void k_cg_schur(int n_blocks, const int32_t *__restrict__ bptr, const int32_t *__restrict__ u_ptr,
+__global__ __launch_bounds__(CG_THREADS) void k_cg_schur(int n_blocks, const int32_t *__restrict__ bptr, const int32_t *__restrict__ u_ptr,
                                                   const int32_t *__restrict__ u_cols, const int32_t *__restrict__ s_ptr,
                                                   const double *__restrict__ sval, const uint16_t *__restrict__ slidx,
                                                   const int32_t *__restrict__ sinfo, const int64_t *__restrict__ dn_off,
@@ -156,7 +196,7 @@ __global__ __launch_bounds__(CG_THREADS, 4) void k_cg_schur(int n_blocks, const 
                                                   double *H, double rtol, int maxiter, unsigned long long *box, unsigned long long *box_other,
                                                   double *pub_vals, unsigned long long *pub_flag, unsigned long long seq, int *err_dev) {
   __shared__ double gs[CG_MAXB], hs[CG_MAXB], ds[CG_MAXB], hvs[CG_MAXB], xs[CG_MAXB], xst[CG_MAX_UCOLS];
-  __shared__ double sh[2][8], bc[CG_NV];
+  __shared__ double sh[4][CG_NV * 8], bc[CG_NV];
   __shared__ int s_err;
   const int wg = blockIdx.x, tid = threadIdx.x, nwg = gridDim.x;
   if (tid == 0) s_err = 0;
@@ -166,31 +206,40 @@ __global__ __launch_bounds__(CG_THREADS, 4) void k_cg_schur(int n_blocks, const 
   const int u0 = u_ptr[wg], nu = u_ptr[wg + 1] - u0;
   // slabs of this block: the even 16-row rounds first (half 0 of the workgroup), then the odd ones (half 1)
   const int half = tid >> 8, ht = tid & 255;
-  const int s0 = s_ptr[3 * wg + half], s1 = s_ptr[3 * wg + half + 1];
+  const int s0 = s_ptr[3 * wg + half], s1 = s_ptr[3 * wg + (CG_THREADS == 512 ? half + 1 : 2)];
   const double *Pb = P + dn_off[wg];
-  const int grp = tid >> 4, lane = tid & 15;  // 32 row groups of 16 lanes in the dense product
+  const int grp = tid >> 4, lane = tid & 15;  // CG_NG row groups of 16 lanes in the dense product
   const bool own = tid < nb;
   int e = 0;
-  // the block's unique columns stay in registers for the whole solve (nu <= CG_MAX_UCOLS = 2 x 512)
-  int ucol[2];
+  // the block's unique columns stay in registers for the whole solve (nu <= CG_MAX_UCOLS)
+  constexpr int NU = CG_MAX_UCOLS / CG_THREADS;
+  int ucol[NU];
 #pragma unroll
-  for (int k = 0; k < 2; ++k) ucol[k] = tid + CG_THREADS * k < nu ? u_cols[u0 + tid + CG_THREADS * k] : -1;
+  for (int k = 0; k < NU; ++k) ucol[k] = tid + CG_THREADS * k < nu ? u_cols[u0 + tid + CG_THREADS * k] : -1;
   if (tid < CG_MAXB) gs[tid] = 0.0;  // rows beyond nb stay 0: the dense product reads gs[] unguarded
 
   // h = P_b g on the block, 16 lanes per row (32 rows at a time); result in hs[] and (write-through) in H.  Blocks of up to
-  // 128 rows (the usual case) keep the loads of two rows in flight; larger ones use one register set of twice the width.
-  auto apply_P = [&]() {
-    if (nb <= 128) {
-      double pa[8], pb[8];
-      auto fetch = [&](int q, double(&pv)[8]) {
-        const bool live = q < nb;
-        const double *prow = Pb + (size_t)(live ? q : 0) * nb;
+  // 128 rows (the usual case) keep the loads of two rows in flight, and the first two rows are fetched by prefetch_P() while
+  // the exchange in front of the product is still in the air (P does not depend on its result); larger blocks use one
+  // register set of twice the width.
+  double pa[8], pb[8];
+  auto fetch = [&](int q, double(&pv)[8]) {
+    const bool live = q < nb;
+    const double *prow = Pb + (size_t)(live ? q : 0) * nb;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const int j = lane + 16 * c;
-          pv[c] = (live && j < nb) ? prow[j] : 0.0;
-        }
-      };
+    for (int c = 0; c < 8; ++c) {
+      const int j = lane + 16 * c;
+      pv[c] = (live && j < nb) ? prow[j] : 0.0;
+    }
+  };
+  auto prefetch_P = [&]() {
+    if (nb <= 128) {
+      fetch(grp, pa);
+      fetch(grp + CG_NG, pb);
+    }
+  };
+  auto apply_P = [&]() {  // prefetch_P() has been called
+    if (nb <= 128) {
       auto use = [&](int q, const double(&pv)[8]) {
         if (q >= nb) return;
         double acc = 0.0;
@@ -199,16 +248,14 @@ __global__ __launch_bounds__(CG_THREADS, 4) void k_cg_schur(int n_blocks, const 
         acc = cg_group_sum<16>(acc);
         if (lane == 0) hs[q] = acc;
       };
-      fetch(grp, pa);
-      fetch(grp + 32, pb);
-      for (int q = grp; q < nb; q += 64) {
+      for (int q = grp; q < nb; q += 2 * CG_NG) {
         use(q, pa);
-        fetch(q + 64, pa);
-        use(q + 32, pb);
-        fetch(q + 96, pb);
+        fetch(q + 2 * CG_NG, pa);
+        use(q + CG_NG, pb);
+        fetch(q + 3 * CG_NG, pb);
       }
     } else {
-      for (int q = grp; q < nb; q += 32) {
+      for (int q = grp; q < nb; q += CG_NG) {
         const double *prow = Pb + (size_t)q * nb;
         double pv[16];
 #pragma unroll
@@ -234,18 +281,24 @@ __global__ __launch_bounds__(CG_THREADS, 4) void k_cg_schur(int n_blocks, const 
     bi = b[r0 + tid];
   }
 #pragma unroll
-  for (int k = 0; k < 2; ++k)
+  for (int k = 0; k < NU; ++k)
     if (ucol[k] >= 0) xst[tid + CG_THREADS * k] = x[ucol[k]];
+  double va[CG_PF];
+  int la[CG_PF];
+  cg_spmv_prefetch(s0, s1, sval, slidx, ht, va, la);
   __syncthreads();
-  cg_block_spmv(s0, s1, sval, slidx, sinfo, xst, hvs, ht);
+  cg_block_spmv(s0, s1, sval, slidx, sinfo, xst, hvs, ht, va, la);
   __syncthreads();
+  prefetch_P();
   if (own) gs[tid] = hvs[tid] - bi;
   __syncthreads();
   apply_P();
   double tot3[3];
   {
     const double part[3] = {own ? gs[tid] * gs[tid] : 0.0, own ? bi * bi : 0.0, own ? gs[tid] * hs[tid] : 0.0};
-    if (!cg_exchange<3>(part, tot3, box, e++, nwg, sh, bc, &s_err)) {
+    cg_post<3>(part, box, e, nwg, sh, &s_err);
+    cg_spmv_prefetch(s0, s1, sval, slidx, ht, va, la);  // the operator values of the first iteration ride on the exchange
+    if (!cg_collect<3>(tot3, box, e++, bc, &s_err)) {
       if (tid == 0) __hip_atomic_store(err_dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (wg == 0 && tid == 0) {
         __hip_atomic_store(pub_vals + 2, 3.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -267,7 +320,7 @@ __global__ __launch_bounds__(CG_THREADS, 4) void k_cg_schur(int n_blocks, const 
     double *Dc = (it & 1) ? D1 : D0;
     // ---- A: h = A d, d = -h(old) in the first iteration, beta d(old) - h(old) afterwards, evaluated for the block's columns
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < NU; ++k)
       if (ucol[k] >= 0) {
         const int j = ucol[k];
         xst[tid + CG_THREADS * k] = it == 1 ? -ld_agent(H + j) : __builtin_fma(beta, ld_agent(Dp + j), -ld_agent(H + j));  // the owner's expression
@@ -278,12 +331,14 @@ __global__ __launch_bounds__(CG_THREADS, 4) void k_cg_schur(int n_blocks, const 
       st_agent(Dc + r0 + tid, dcur);
     }
     __syncthreads();
-    cg_block_spmv(s0, s1, sval, slidx, sinfo, xst, hvs, ht);
+    cg_block_spmv(s0, s1, sval, slidx, sinfo, xst, hvs, ht, va, la);
     __syncthreads();
     double tot1[1];
     {
       const double part[1] = {own ? ds[tid] * hvs[tid] : 0.0};
-      if (!cg_exchange<1>(part, tot1, box, e++, nwg, sh, bc, &s_err)) {
+      cg_post<1>(part, box, e, nwg, sh, &s_err);
+      prefetch_P();  // rides on the exchange's round trips
+      if (!cg_collect<1>(tot1, box, e++, bc, &s_err)) {
         dead = true;
         break;
       }
@@ -299,7 +354,9 @@ __global__ __launch_bounds__(CG_THREADS, 4) void k_cg_schur(int n_blocks, const 
     double tot2[2];
     {
       const double part[2] = {own ? gs[tid] * gs[tid] : 0.0, own ? gs[tid] * hs[tid] : 0.0};
-      if (!cg_exchange<2>(part, tot2, box, e++, nwg, sh, bc, &s_err)) {
+      cg_post<2>(part, box, e, nwg, sh, &s_err);
+      cg_spmv_prefetch(s0, s1, sval, slidx, ht, va, la);  // next iteration's operator values (wasted once, in the last iteration)
+      if (!cg_collect<2>(tot2, box, e++, bc, &s_err)) {
         dead = true;
         break;
       }

@@ -25,22 +25,20 @@ __device__ __forceinline__ void gx_post(unsigned long long *p, double v) {
 __device__ __forceinline__ void gx_clear(unsigned long long *p) {
   __hip_atomic_store(p, GX_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// wait for a mailbox word; *err is raised (and 0 returned) after the timeout.  Three polls are kept in flight, so a value
-// is seen about a third of a memory round trip after it lands instead of (on average) half a round trip plus the next one.
+// wait for a mailbox word; *err is raised (and 0 returned) after the timeout.  One poll in flight at a time: keeping three in
+// flight (bunched or evenly spaced) measured 0.2 - 0.6 us SLOWER per exchange (tools/exchange_bench.hip): the extra requests
+// queue in front of the answer.
 __device__ __forceinline__ unsigned long long gx_load(const unsigned long long *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ unsigned long long gx_wait(const unsigned long long *p, int *err) {
-  unsigned long long b0 = gx_load(p);
-  if (b0 != GX_EMPTY) return b0;
-  unsigned long long b1 = gx_load(p), b2 = gx_load(p);
-  b0 = gx_load(p);
+  unsigned long long b = gx_load(p);
+  if (b != GX_EMPTY) return b;
   unsigned long long t0 = 0;
   for (unsigned int spin = 1;; ++spin) {
-    if (b1 != GX_EMPTY) return b1;
-    b1 = b2;
-    b2 = b0;
-    b0 = gx_load(p);
+    __builtin_amdgcn_s_sleep(1);
+    b = gx_load(p);
+    if (b != GX_EMPTY) return b;
     if ((spin & 255u) == 0) {  // the clock is a scalar memory read: look at it rarely
       const unsigned long long now = wall_clock64();
       if (t0 == 0) t0 = now;
@@ -50,6 +48,32 @@ __device__ __forceinline__ unsigned long long gx_wait(const unsigned long long *
       }
     }
   }
+}
+// the same for N words `stride` apart, all polled together: one round trip per poll round, not one per word
+template <int N>
+__device__ __forceinline__ void gx_wait_n(const unsigned long long *p, size_t stride, double (&out)[N], int *err) {
+  unsigned long long b[N], t0 = 0;
+  for (unsigned int spin = 1;; ++spin) {
+    bool all = true;
+#pragma unroll
+    for (int v = 0; v < N; ++v) b[v] = gx_load(p + (size_t)v * stride);
+#pragma unroll
+    for (int v = 0; v < N; ++v) all = all && b[v] != GX_EMPTY;
+    if (all) break;
+    __builtin_amdgcn_s_sleep(1);
+    if ((spin & 255u) == 0) {
+      const unsigned long long now = wall_clock64();
+      if (t0 == 0) t0 = now;
+      else if (now - t0 > GX_TIMEOUT_TICKS) {
+        *err = 1;
+#pragma unroll
+        for (int v = 0; v < N; ++v) b[v] = 0;
+        break;
+      }
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < N; ++v) out[v] = __longlong_as_double((long long)b[v]);
 }
 __device__ __forceinline__ double gx_wait_value(const unsigned long long *p, int *err) { return __longlong_as_double((long long)gx_wait(p, err)); }
 

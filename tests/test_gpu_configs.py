@@ -1,0 +1,108 @@
+"""BASELINE.json configs[3] and configs[4] at the sizes ONE MI355X allows (tests need a real MI355X):
+  * configs[4]: Re = 100 unsteady run (u_m = 2.25, NavierStokes3D.hpp:37,80 with the Schaefer-Turek 3D-2Z inflow), drag / lift
+    coefficient SERIES over consecutive steps, device against oracle to 1e-8 per step (north_star's drag/lift claim);
+  * configs[3]: the ~10 M-DoF mesh of the 8-GPU configuration on one GPU (13 GB of the 288): operator identities and one
+    time step, as tests/test_gpu_fullsize.py does at 1 M DoF."""
+import numpy as np
+import pytest
+
+from conftest import Problem
+
+pytestmark = pytest.mark.gpu
+
+
+def test_re100_drag_lift_series_matches_oracle():
+    import navierstokes_project_nm4pde_amd.nsx as nsx
+    from navierstokes_project_nm4pde_amd.frontend import Tables
+    from navierstokes_project_nm4pde_amd.problem import InletVelocity, cylinder_boundary_values, force_coefficients, obstacle_faces
+    p = Problem("cylinder", 3, 1, n_sub=6, ordering="colour")
+    dev, ora = p.device(), p.oracle()
+    inlet = InletVelocity(3, test_case=2, u_m=2.25)         # mean inflow 4/9 u_m = 1 m/s, D = 0.1, nu = 1e-3: Re = 100
+    assert abs(inlet.mean_velocity() - 1.0) < 1e-15
+    cells, lf = obstacle_faces(p.mesh)
+    ftab = Tables(3, Tables.FACE)
+    dev.set_force_faces(cells, lf, ftab)
+    u0 = np.zeros(p.dofs.n_dofs)
+    dev.set_solution(u0)
+    n_steps, t = 20, 0.0
+    series = []
+    for step in range(n_steps):
+        t += p.deltat
+        bd, bv = cylinder_boundary_values(p.dofs, inlet, t)
+        for o in (dev, ora):
+            if step == 0:
+                o.assemble(nsx.TEMAM)                         # NavierStokes3D.cpp:721
+            else:
+                o.assemble_time_step(0)                       # :722
+            o.apply_boundary_values(bd, bv)
+        sd = dev.solve_time_step(nsx.YOSIDA, tol_abs=1e-12, inner_rtol=1e-10)
+        so = ora.solve_time_step(nsx.YOSIDA, tol_abs=1e-12, inner_rtol=1e-10)
+        assert sd["status"] == 0 and so["status"] == 0
+        fd, fo = dev.compute_forces(), ora.compute_forces(cells, lf, ftab)   # NavierStokes3D.cpp:728-733, 744-846
+        cd = force_coefficients(3, *fd, mean_v=inlet.mean_velocity())
+        co = force_coefficients(3, *fo, mean_v=inlet.mean_velocity())
+        series.append((cd, co))
+        scale = max(1.0, abs(co[0]), abs(co[1]))
+        assert abs(cd[0] - co[0]) < 1e-8 * scale, (step, cd, co)
+        assert abs(cd[1] - co[1]) < 1e-8 * scale, (step, cd, co)
+        assert np.abs(dev.solution_owned - ora.solution_owned).max() < 1e-8 * np.abs(ora.solution_owned).max()
+    cds = np.array([s[0][0] for s in series])
+    assert np.isfinite(cds).all() and cds[-1] > 0 and np.ptp(cds) > 0   # a developing flow: drag positive and changing in time
+    dev.close()
+
+
+def test_ten_million_dof_mesh_on_one_gpu():
+    from navierstokes_project_nm4pde_amd import nsx
+    from navierstokes_project_nm4pde_amd.frontend import DoFs, Mesh, Tables
+    from navierstokes_project_nm4pde_amd.problem import InletVelocity, cylinder_boundary_values
+    mesh = Mesh.cylinder(3, 14).partition(1, 8 * 4096)      # bench.py's mesh and virtual ranks for --gpus 8
+    d, tables = DoFs(mesh, "colour"), Tables(3)
+    assert 8.0e6 < d.n_dofs < 1.2e7
+    dev = nsx.Nsx(d, tables, 1e-3, 2e-4)
+    dev.set_schur_blocks(d.owned_p_ptr[::8])
+    dt, H = 2e-4, 0.41
+    X = d.support_points
+    rng = np.random.default_rng(4321)
+    u = np.zeros(d.n_dofs)
+    u[0:d.n_u:3] = 16 * 9.0 * X[0:d.n_u:3, 1] * X[0:d.n_u:3, 2] * (H - X[0:d.n_u:3, 1]) * (H - X[0:d.n_u:3, 2]) / H ** 4 \
+        * (1 + 0.1 * np.sin(7 * X[0:d.n_u:3, 0])) + 1e-3 * rng.standard_normal(d.n_u // 3)
+    dev.set_solution(u)
+    dev.assemble(0)
+    e = np.zeros(d.n_dofs)
+    e[0:d.n_u:3] = 1.0
+    y = dev.system_vmult(e)
+    Xm = mesh.vertices[mesh.cells]
+    vol = abs(np.linalg.det(Xm[:, 1:] - Xm[:, :1])).sum() / 6
+    assert abs(y[0:d.n_u:3].sum() * dt - vol) < 1e-9 * vol                 # sum of the mass matrix = |Omega|
+    assert abs(y[1:d.n_u:3]).max() < 1e-12 * abs(y[0:d.n_u:3]).max()       # no cross-component coupling
+    assert abs(y[d.n_u:]).max() < 1e-11 * abs(y[:d.n_u]).max() * dt * 1e4  # divergence of a constant
+    v, q = np.zeros(d.n_dofs), np.zeros(d.n_dofs)
+    v[:d.n_u] = rng.standard_normal(d.n_u)
+    q[d.n_u:] = rng.standard_normal(d.n_p)
+    Av, Aq = dev.system_vmult(v), dev.system_vmult(q)
+    assert abs(Aq[:d.n_u] @ v[:d.n_u] + Av[d.n_u:] @ q[d.n_u:]) < 1e-10 * abs(Av[d.n_u:] @ q[d.n_u:])   # block(0,1) = -block(1,0)^T
+    bd, bv = cylinder_boundary_values(d, InletVelocity(3), dt)
+    dev.apply_boundary_values(bd, bv)
+    b = dev.rhs
+    st = dev.solve_time_step(nsx.YOSIDA)
+    assert st["status"] == 0 and 5 <= st["outer_iterations"] <= 300
+    x = dev.solution_owned
+    r = b - dev.system_vmult(x)
+    assert np.linalg.norm(r) < 2e-2 * np.linalg.norm(b)
+    assert np.abs(x[bd] - bv).max() < 1e-5 * max(1.0, np.abs(bv).max())
+    # ILU^{-1} (L D U v) = v at this size too (velocity blocks), with the device's own factors applied on the host
+    import scipy.sparse as sp
+    rp, ci, lu = dev.ilu(0)
+    n = len(rp) - 1
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    blk_of = np.searchsorted(d.owned_u_ptr, np.arange(n), side="right") - 1
+    keep = blk_of[rows] == blk_of[ci]
+    M = sp.csr_matrix((lu * keep, ci, rp), shape=(n, n))
+    L = sp.tril(M, -1).tocsr() + sp.identity(n, format="csr")
+    U = sp.triu(M, 1).tocsr() + sp.identity(n, format="csr")
+    dinv = M.diagonal()
+    vv = rng.standard_normal((n, 3))
+    w = L @ ((U @ vv) / dinv[:, None])
+    z = dev.ilu_apply(0, w.ravel())
+    assert np.abs(z.reshape(n, 3) - vv).max() < 1e-9 * np.abs(vv).max()
+    dev.close()
