@@ -269,10 +269,10 @@ def summarise_kernels(table, prof_stats):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10,
-                    help="timed time steps (GMRES(28) needs a restart in some steps and not in others: 25 or 50 outer "
-                         "iterations; ten steps average over that)")
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20,
+                    help="timed time steps (GMRES(28) needs a restart in some steps and not in others: 20 - 28 or 45 - 55 outer "
+                         "iterations, and restart steps come in runs; see gmres_outer_iters_per_step / ms_per_outer_iteration)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--level", type=int, default=None, help="mesh level (default: 7 ~ 1.09M DoF per GPU)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak", help="which figure becomes `value` for N > 1 (both are reported)")
     ap.add_argument("--ranks", type=int, default=4096, help="virtual MPI ranks = ILU(0) blocks of F")
@@ -389,6 +389,8 @@ def main():
                    "n_dofs": dofs.n_dofs, "n_cells": dofs.n_cells,
                    "parallelism": "mesh partitioned over %d GPU(s): RCCL ghost exchange + dot-product all-reduce" % world},
         "gmres_outer_iters_per_step": outer / n,
+        "ms_per_outer_iteration": 1e3 * elapsed / max(1, outer),
+        "outer_iters_of_each_timed_step": [s["outer_iterations"] for s in stats],
         "gmres_outer_iters_per_sec": outer / t_solve if t_solve > 0 else None,
         "inner_F_iters_per_step": sum(s["inner_F_iterations"] for s in stats) / n,
         "inner_S_iters_per_step": sum(s["inner_S_iterations"] for s in stats) / n,

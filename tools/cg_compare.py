@@ -1,0 +1,51 @@
+"""Development check: the persistent Schur CG against the launch-per-operation CG on the bench problem (same state, same
+right-hand sides, reference tolerance 1e-2): iteration counts and results of Yosida's vmult."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from navierstokes_project_nm4pde_amd import nsx  # noqa: E402
+from navierstokes_project_nm4pde_amd.problem import InletVelocity, cylinder_boundary_values  # noqa: E402
+
+level = int(sys.argv[1]) if len(sys.argv) > 1 else 7
+mesh, dofs, tables = bench.build_problem(level, 4096, 1, "colour")
+inlet = InletVelocity(3)
+os.environ["NSX_CG_PERSISTENT"] = "0"
+dev = nsx.Nsx(dofs, tables, 1e-3, 2e-4)  # a developed state to start both variants from
+dev.set_schur_blocks(bench.schur_block_table(dofs, 512))
+dev.set_solution(np.zeros(dofs.n_dofs))
+t = 0.0
+for step in range(3):
+    t += 2e-4
+    dev.assemble(nsx.TEMAM) if step == 0 else dev.assemble_time_step(0)
+    dev.apply_boundary_values(*cylinder_boundary_values(dofs, inlet, t))
+    dev.solve_time_step(nsx.YOSIDA)
+state = dev.solution_owned
+dev.close()
+res = {}
+for flag in ("0", "1"):
+    os.environ["NSX_CG_PERSISTENT"] = flag
+    dev = nsx.Nsx(dofs, tables, 1e-3, 2e-4)
+    dev.set_schur_blocks(bench.schur_block_table(dofs, 512))
+    dev.set_solution(state)
+    dev.assemble(nsx.TEMAM)
+    dev.apply_boundary_values(*cylinder_boundary_values(dofs, inlet, t + 2e-4))
+    dev.prec_initialize(nsx.YOSIDA)
+    rng = np.random.default_rng(5)
+    out = []
+    for k in range(4):
+        src = rng.standard_normal(dofs.n_dofs)
+        y, st = dev.prec_vmult(nsx.YOSIDA, src, inner_rtol=1e-2)
+        out.append((y, st["inner_S_iterations"], st["inner_F_iterations"]))
+    st = dev.solve_time_step(nsx.YOSIDA)
+    print("flag", flag, "full step:", st["outer_iterations"], st["inner_F_iterations"], st["inner_S_iterations"], st["n_S_solves"])
+    res[flag] = out
+    dev.close()
+for k in range(4):
+    y0, s0, f0 = res["0"][k]
+    y1, s1, f1 = res["1"][k]
+    print("rhs %d: S iterations chain %d persistent %d | F iterations %d %d | rel diff of vmult %.3e" %
+          (k, s0, s1, f0, f1, np.abs(y0 - y1).max() / np.abs(y0).max()))
