@@ -62,9 +62,9 @@ def pmc_traffic(scope):
     return None, None
 
 
-def build_problem(level, ranks, world=1, ordering="colour"):
+def build_problem(level, ranks, world=1, ordering="colour", balance="cells"):
     from navierstokes_project_nm4pde_amd.frontend import DoFs, Mesh, Tables
-    mesh = Mesh.cylinder(3, level).partition(world, max(1, ranks // world))
+    mesh = Mesh.cylinder(3, level).partition(world, max(1, ranks // world), balance=balance)
     return mesh, DoFs(mesh, ordering), Tables(3)
 
 

@@ -61,6 +61,10 @@ const int32_t *nsxh_mesh_subdomain(const nsxh_mesh *); /* [n_cells] */
  * NavierStokes3D.cpp:16): first n_parts "ranks" (GPUs), then n_sub blocks inside each.
  * subdomain id = part * n_sub + sub. */
 int nsxh_mesh_partition(nsxh_mesh *, int n_parts, int n_sub);
+/* The same bisection with the cuts placed so that the subdomains OWN equal numbers of vertices under deal.II's rule
+ * "an interface node belongs to the lowest subdomain id touching it" (equal cell counts give the low ids up to twice the
+ * mean).  Equal ILU(0) blocks are what the wave-per-block triangular solve wants; the cell counts then differ. */
+int nsxh_mesh_partition_owned(nsxh_mesh *, int n_parts, int n_sub);
 
 /* ---- DoF handler: Taylor-Hood P2/P1 (FESystem(FE_SimplexP(2)^dim, FE_SimplexP(1)), reference NavierStokes3D.cpp:31-36) ---- */
 

@@ -294,6 +294,7 @@ void spmv_B(nsx_handle *h, const double *xu, double *yp);                       
 void spmv_S(nsx_handle *h, const double *x, double *y);                                     // y = negative_S x
 void schur_numeric(nsx_handle *h, const double *w);                                         // S = B diag(w) G
 void ilu_factor(nsx_handle *h, const DevCsr &g, IluSchedule &s, const double *vals, double *lu, const char *name);
+void ilu_check(nsx_handle *h);  // after a synchronisation: throws if a factorisation kernel reported a failure
 // dot_slot >= 0: also leave b.x in that scalar slot when the packed kernel can do it; returns whether it did
 bool ilu_solve(nsx_handle *h, const DevCsr &g, const IluSchedule &s, const double *lu, const double *b, double *x, int ncomp,
                const char *name, int dot_slot = -1);

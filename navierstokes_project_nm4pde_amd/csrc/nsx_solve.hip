@@ -361,6 +361,7 @@ void solve_time_step(nsx_handle *h, int type, double tol, double inner_rtol, int
   double t0 = now_s();
   prec_initialize(h, type);  // NS3D.cpp:568-569
   HIP_CHECK(hipStreamSynchronize(h->stream));
+  ilu_check(h);
   st->t_prec = now_s() - t0;
   t0 = now_s();
   Op A = [h](double *d, const double *s) { spmv_saddle(h, s, d); };
@@ -418,6 +419,7 @@ int nsx_prec_initialize(nsx_handle *h, int prec_type) {
   NSX_API_BODY(h, {
     nsx::prec_initialize(h, prec_type);
     HIP_CHECK(hipStreamSynchronize(h->stream));
+    nsx::ilu_check(h);
   })
 }
 

@@ -401,7 +401,7 @@ __global__ __launch_bounds__(ILU_WAVES * 64) void k_ilu_factor(const int32_t *__
       const int i = lvl_rows[l0 + r];
       const int p0 = rp[i], n = rp[i + 1] - p0, dpos = diag[i] - p0;
       if (n > ILU_MAXROW) {
-        if (lane == 0) *err = 1;
+        if (lane == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         continue;
       }
       for (int t = lane; t < n; t += 64) {
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(ILU_WAVES * 64) void k_ilu_factor(const int32_t *__
       }
       const double d = w[dpos];
       const double dinv = 1.0 / d;
-      if (lane == 0 && !(fabs(d) > 0.0)) *err = 2;
+      if (lane == 0 && !(fabs(d) > 0.0)) __hip_atomic_store(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       for (int t = lane; t < n; t += 64) {
         const int j = ci[p0 + t];
         double v = w[t];
@@ -479,6 +479,46 @@ __global__ __launch_bounds__(256) void k_ilu_invert(const int32_t *__restrict__ 
       Pb[(size_t)i * n + j] = acc;
     }
   }
+}
+
+// The same inverse, tiled: one wave per (block, tile of 32 columns), the tile Y[n][32] in LDS.  The factor entries of a row are
+// the same for all columns, so the only per-column traffic is LDS; the two halves of the wave split the entries of a row
+// (even / odd) and add their sums.  Column j of L^-1 is zero above row j, so the forward sweep of a tile starts at its first
+// column.  Same operations per entry as k_ilu_invert up to the order of the two partial sums.
+constexpr int INV_TILE = 32;
+__global__ __launch_bounds__(64) void k_ilu_invert_tiled(const int32_t *__restrict__ bptr, const int64_t *__restrict__ off,
+                                                         const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                         const int32_t *__restrict__ diag, const double *__restrict__ lu, double *__restrict__ P) {
+  extern __shared__ double Y[];  // [n][INV_TILE]
+  const int blk = blockIdx.x, r0 = bptr[blk], n = bptr[blk + 1] - r0;
+  const int j0 = blockIdx.y * INV_TILE;
+  if (j0 >= n) return;
+  const int lane = threadIdx.x & 31, half = threadIdx.x >> 5, j = j0 + lane;
+  for (int t = threadIdx.x; t < j0 * INV_TILE; t += 64) Y[t] = 0.0;  // rows above the tile's first column
+  for (int i = j0; i < n; ++i) {  // Y = L^-1 (unit lower)
+    const int row = r0 + i, pe = diag[row];
+    double acc = 0.0;
+    for (int p = rp[row] + half; p < pe; p += 2) {
+      const int k = ci[p] - r0;
+      if (k >= 0) acc += lu[p] * Y[k * INV_TILE + lane];
+    }
+    acc += __shfl_xor(acc, 32, 64);
+    if (half == 0) Y[i * INV_TILE + lane] = (i == j ? 1.0 : 0.0) - acc;
+  }
+  for (int i = n - 1; i >= 0; --i) {  // P = U^-1 (D^-1 Y), in place from the last row up
+    const int row = r0 + i, pd = diag[row], pe = rp[row + 1];
+    double acc = 0.0;
+    for (int p = pd + 1 + half; p < pe; p += 2) {
+      const int k = ci[p] - r0;
+      if (k < n) acc += lu[p] * Y[k * INV_TILE + lane];
+    }
+    acc += __shfl_xor(acc, 32, 64);
+    const double v = lu[pd] * Y[i * INV_TILE + lane] - acc;
+    if (half == 0) Y[i * INV_TILE + lane] = v;
+  }
+  double *Pb = P + off[blk];
+  for (int i = half; i < n; i += 2)
+    if (j < n) Pb[(size_t)i * n + j] = Y[i * INV_TILE + lane];
 }
 
 // x_b = P_b b_b: 16 lanes per row, 64 row groups per workgroup (a ~100-row block is done in two rounds: the kernel is
@@ -572,7 +612,7 @@ __global__ __launch_bounds__(ILU_WAVES * 64) void k_ilu_factor_small(const int32
       }
       const double d = w[i - r0];
       const double dinv = 1.0 / d;
-      if (lane == 0 && !(fabs(d) > 0.0)) *err = 2;
+      if (lane == 0 && !(fabs(d) > 0.0)) __hip_atomic_store(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       for (int t = lane; t < n; t += 64) {
         const int j = ci[p0 + t], c = j - r0;
         const bool in = c >= 0 && c < nb;
@@ -608,7 +648,7 @@ __global__ __launch_bounds__(ILU_WAVES * 64) void k_ilu_factor_level(int n_lvl_r
   volatile double *w = wv[wave];
   const int p0 = rp[i], n = rp[i + 1] - p0, dpos = diag[i] - p0, lo = in_lo[i] - p0, hi = in_hi[i] - p0;
   if (n > ILU_MAXROW) {
-    if (lane == 0) *err = 1;
+    if (lane == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return;
   }
   for (int t = lane; t < n; t += 64) w[t] = (t >= lo && t < hi) ? a[p0 + t] : 0.0;
@@ -632,7 +672,7 @@ __global__ __launch_bounds__(ILU_WAVES * 64) void k_ilu_factor_level(int n_lvl_r
   }
   const double d = w[dpos];
   const double dinv = 1.0 / d;
-  if (lane == 0 && !(fabs(d) > 0.0)) *err = 2;
+  if (lane == 0 && !(fabs(d) > 0.0)) __hip_atomic_store(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   for (int t = lane; t < n; t += 64) {
     double v = w[t];
     if (t == dpos) v = dinv;
@@ -691,9 +731,19 @@ static void ilu_solve_levelled(nsx_handle *h, const DevCsr &g, const IluSchedule
   }
 }
 
+// The factorisation kernels report a failure (row too long, zero pivot) through a word in mapped host memory, written only
+// when something is wrong; ilu_check() looks at it after the caller's next synchronisation (no stream sync, no copy here).
+void ilu_check(nsx_handle *h) {
+  volatile int *err = (volatile int *)(h->pub_host + N_SLOTS + 3);
+  const int herr = *err;
+  if (!herr) return;
+  *err = 0;
+  if (herr == 1) NSX_THROW(NSX_ERR_UNSUPPORTED, "ILU: a row has more than %d entries", ILU_MAXROW);
+  NSX_THROW(NSX_ERR_NUMERIC, "ILU: zero pivot");
+}
+
 void ilu_factor(nsx_handle *h, const DevCsr &g, IluSchedule &s, const double *vals, double *lu, const char *name) {
-  int *err = (int *)(h->scal.p + (N_SLOTS - 1));
-  HIP_CHECK(hipMemsetAsync(err, 0, sizeof(double), h->stream));
+  int *err = (int *)(h->pub_dev + N_SLOTS + 3);
   {
     LaunchScope ls(h, name, 20.0 * g.nnz() + 12.0 * g.n_rows());
     static const bool small_ok = !(getenv("NSX_ILU_SMALL") && atoi(getenv("NSX_ILU_SMALL")) == 0);
@@ -713,15 +763,15 @@ void ilu_factor(nsx_handle *h, const DevCsr &g, IluSchedule &s, const double *va
                          s.fwd_rows.p, g.rowptr.p, g.colind.p, g.diag.p, vals, lu, s.packed_ok ? s.pk_slot_of.p : nullptr, s.pk_val.p,
                          s.pk_dinv.p, err);
   }
-  int herr = 0;
-  HIP_CHECK(hipMemcpyAsync(&herr, err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  HIP_CHECK(hipStreamSynchronize(h->stream));
-  if (herr == 1) NSX_THROW(NSX_ERR_UNSUPPORTED, "ILU: a row has more than %d entries", ILU_MAXROW);
-  if (herr == 2) NSX_THROW(NSX_ERR_NUMERIC, "ILU: zero pivot");
   if (s.dense) {
     LaunchScope ls(h, "ilu_invert", 8.0 * (double)s.dn_entries + 12.0 * g.nnz());
-    hipLaunchKernelGGL(k_ilu_invert, dim3(s.n_blocks), dim3(256), 0, h->stream, s.block_ptr.p, s.dn_off.p, g.rowptr.p, g.colind.p, g.diag.p, lu,
-                       s.dn_P.p);
+    const size_t shm = (size_t)s.max_rows * INV_TILE * sizeof(double);
+    if (shm <= 64 * 1024)
+      hipLaunchKernelGGL(k_ilu_invert_tiled, dim3(s.n_blocks, cdiv(s.max_rows, INV_TILE)), dim3(64), shm, h->stream, s.block_ptr.p, s.dn_off.p, g.rowptr.p,
+                         g.colind.p, g.diag.p, lu, s.dn_P.p);
+    else
+      hipLaunchKernelGGL(k_ilu_invert, dim3(s.n_blocks), dim3(256), 0, h->stream, s.block_ptr.p, s.dn_off.p, g.rowptr.p, g.colind.p, g.diag.p, lu,
+                         s.dn_P.p);
   }
 }
 

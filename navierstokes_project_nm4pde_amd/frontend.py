@@ -36,6 +36,7 @@ def _lib():
         "nsxh_mesh_bface_cells": (_i32p, [vp]),
         "nsxh_mesh_subdomain": (_i32p, [vp]),
         "nsxh_mesh_partition": (C.c_int, [vp, C.c_int, C.c_int]),
+        "nsxh_mesh_partition_owned": (C.c_int, [vp, C.c_int, C.c_int]),
         "nsxh_distribute_dofs": (vp, [vp]),
         "nsxh_distribute_dofs_ordered": (vp, [vp, C.c_int]),
         "nsxh_n_colours": (C.c_int, [vp]),
@@ -136,8 +137,10 @@ class Mesh:
     def read_msh(cls, path):
         return cls(_lib().nsxh_mesh_read_msh(str(path).encode()))
 
-    def partition(self, n_parts=1, n_sub=1):
-        rc = self._lib.nsxh_mesh_partition(self._h, n_parts, n_sub)
+    def partition(self, n_parts=1, n_sub=1, balance="cells"):
+        """balance = "cells": equal cell counts (METIS-like); "owned": equal numbers of owned nodes per subdomain."""
+        fn = self._lib.nsxh_mesh_partition_owned if balance == "owned" else self._lib.nsxh_mesh_partition
+        rc = fn(self._h, n_parts, n_sub)
         if rc != 0:
             raise ValueError("partition failed (rc=%d)" % rc)
         self.refresh()
