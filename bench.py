@@ -284,6 +284,8 @@ def main():
     ap.add_argument("--schur-blocks", type=int, default=512, help="ILU(0) blocks of the Schur matrix")
     ap.add_argument("--ordering", choices=("colour", "first_touch"), default="colour",
                     help="velocity node order inside a virtual rank (include/nsx_host.h: nsxh_distribute_dofs_ordered)")
+    ap.add_argument("--balance", choices=("cells", "owned"), default="cells",
+                    help="what the partitioner equalises over the virtual ranks: cells (METIS-like) or owned P2 nodes = ILU block sizes")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-only", action="store_true", help="only the cpu_baseline leg (after a short GPU run that provides its state)")
     ap.add_argument("--layout-table", metavar="FILE", help="write the preconditioner-layout iteration table to FILE and exit")
@@ -331,7 +333,7 @@ def main():
     def partitioned_run(level, ranks, schur, steps, warmup, profile_steps, want_state=False):
         """every rank runs its part; a failure anywhere ends the job with a non-zero exit code (the launcher tears the
         group down) — a GPU fault must be investigated, not converted into a throughput number"""
-        mesh, dofs, tables = build_problem(level, ranks, world, args.ordering)
+        mesh, dofs, tables = build_problem(level, ranks, world, args.ordering, args.balance)
         try:
             el, stats, table, prof_stats, state = gpu_run(dofs, tables, steps, warmup, schur, local_rank, profile_steps=profile_steps,
                                                           barrier=barrier, rank=rank, world=world, want_state=want_state, spinup=args.spinup)

@@ -457,7 +457,9 @@ void ensure_schedules(nsx_handle *h) {
 
 }  // namespace nsx
 
-#define NSX_TRY(h_) try {
+#define NSX_TRY(h_)                 \
+  if (!(h_)) return NSX_ERR_ARG;    \
+  try {
 #define NSX_CATCH(h_)                                      \
   }                                                        \
   catch (const nsx::Error &e) {                            \
@@ -856,6 +858,8 @@ int nsx_set_schur_blocks(nsx_handle *h, int n_blocks, const int32_t *p_ptr) {
   NSX_TRY(h)
   if (!h->have_mesh) NSX_THROW(NSX_ERR_ARG, "nsx_set_mesh first");
   if (n_blocks < 1 || !p_ptr || p_ptr[0] != h->goff_p || p_ptr[n_blocks] != h->goff_p + h->NP) NSX_THROW(NSX_ERR_ARG, "bad Schur block table");
+  for (int r = 0; r < n_blocks; ++r)
+    if (p_ptr[r + 1] < p_ptr[r]) NSX_THROW(NSX_ERR_ARG, "Schur block ranges must be ascending");
   HIP_CHECK(hipSetDevice(h->prm.device));
   h->sblk_h.resize((size_t)n_blocks + 1);
   for (int r = 0; r <= n_blocks; ++r) h->sblk_h[r] = p_ptr[r] - h->goff_p;
@@ -898,15 +902,15 @@ static int vec_io(nsx_handle *h, nsx::DevBuf<double> &v, double *out, const doub
 }
 
 int nsx_set_solution(nsx_handle *h, const double *s) {
-  if (!s) return NSX_ERR_ARG;
+  if (!h || !s) return NSX_ERR_ARG;
   int rc = vec_io(h, h->sol_owned, nullptr, s);
   if (rc) return rc;
   return vec_io(h, h->sol, nullptr, s);
 }
-int nsx_get_solution(nsx_handle *h, double *s) { return vec_io(h, h->sol_owned, s, nullptr); }
-int nsx_get_solution_ghosted(nsx_handle *h, double *s) { return vec_io(h, h->sol, s, nullptr); }
-int nsx_get_rhs(nsx_handle *h, double *s) { return vec_io(h, h->rhs, s, nullptr); }
-int nsx_set_rhs(nsx_handle *h, const double *s) { return s ? vec_io(h, h->rhs, nullptr, s) : NSX_ERR_ARG; }
+int nsx_get_solution(nsx_handle *h, double *s) { return h ? vec_io(h, h->sol_owned, s, nullptr) : NSX_ERR_ARG; }
+int nsx_get_solution_ghosted(nsx_handle *h, double *s) { return h ? vec_io(h, h->sol, s, nullptr) : NSX_ERR_ARG; }
+int nsx_get_rhs(nsx_handle *h, double *s) { return h ? vec_io(h, h->rhs, s, nullptr) : NSX_ERR_ARG; }
+int nsx_set_rhs(nsx_handle *h, const double *s) { return (h && s) ? vec_io(h, h->rhs, nullptr, s) : NSX_ERR_ARG; }
 
 // ---- exports
 int nsx_scalar_graph_nnz(nsx_handle *h, int which, int64_t *nnz) {

@@ -481,46 +481,6 @@ __global__ __launch_bounds__(256) void k_ilu_invert(const int32_t *__restrict__ 
   }
 }
 
-// The same inverse, tiled: one wave per (block, tile of 32 columns), the tile Y[n][32] in LDS.  The factor entries of a row are
-// the same for all columns, so the only per-column traffic is LDS; the two halves of the wave split the entries of a row
-// (even / odd) and add their sums.  Column j of L^-1 is zero above row j, so the forward sweep of a tile starts at its first
-// column.  Same operations per entry as k_ilu_invert up to the order of the two partial sums.
-constexpr int INV_TILE = 32;
-__global__ __launch_bounds__(64) void k_ilu_invert_tiled(const int32_t *__restrict__ bptr, const int64_t *__restrict__ off,
-                                                         const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
-                                                         const int32_t *__restrict__ diag, const double *__restrict__ lu, double *__restrict__ P) {
-  extern __shared__ double Y[];  // [n][INV_TILE]
-  const int blk = blockIdx.x, r0 = bptr[blk], n = bptr[blk + 1] - r0;
-  const int j0 = blockIdx.y * INV_TILE;
-  if (j0 >= n) return;
-  const int lane = threadIdx.x & 31, half = threadIdx.x >> 5, j = j0 + lane;
-  for (int t = threadIdx.x; t < j0 * INV_TILE; t += 64) Y[t] = 0.0;  // rows above the tile's first column
-  for (int i = j0; i < n; ++i) {  // Y = L^-1 (unit lower)
-    const int row = r0 + i, pe = diag[row];
-    double acc = 0.0;
-    for (int p = rp[row] + half; p < pe; p += 2) {
-      const int k = ci[p] - r0;
-      if (k >= 0) acc += lu[p] * Y[k * INV_TILE + lane];
-    }
-    acc += __shfl_xor(acc, 32, 64);
-    if (half == 0) Y[i * INV_TILE + lane] = (i == j ? 1.0 : 0.0) - acc;
-  }
-  for (int i = n - 1; i >= 0; --i) {  // P = U^-1 (D^-1 Y), in place from the last row up
-    const int row = r0 + i, pd = diag[row], pe = rp[row + 1];
-    double acc = 0.0;
-    for (int p = pd + 1 + half; p < pe; p += 2) {
-      const int k = ci[p] - r0;
-      if (k < n) acc += lu[p] * Y[k * INV_TILE + lane];
-    }
-    acc += __shfl_xor(acc, 32, 64);
-    const double v = lu[pd] * Y[i * INV_TILE + lane] - acc;
-    if (half == 0) Y[i * INV_TILE + lane] = v;
-  }
-  double *Pb = P + off[blk];
-  for (int i = half; i < n; i += 2)
-    if (j < n) Pb[(size_t)i * n + j] = Y[i * INV_TILE + lane];
-}
-
 // x_b = P_b b_b: 16 lanes per row, 64 row groups per workgroup (a ~100-row block is done in two rounds: the kernel is
 // bound by load latency, not bytes, so the block gets as many loads in flight as the CU allows); optional b . x partial
 constexpr int DENSE_THREADS = 1024;
@@ -765,13 +725,8 @@ void ilu_factor(nsx_handle *h, const DevCsr &g, IluSchedule &s, const double *va
   }
   if (s.dense) {
     LaunchScope ls(h, "ilu_invert", 8.0 * (double)s.dn_entries + 12.0 * g.nnz());
-    const size_t shm = (size_t)s.max_rows * INV_TILE * sizeof(double);
-    if (shm <= 64 * 1024)
-      hipLaunchKernelGGL(k_ilu_invert_tiled, dim3(s.n_blocks, cdiv(s.max_rows, INV_TILE)), dim3(64), shm, h->stream, s.block_ptr.p, s.dn_off.p, g.rowptr.p,
-                         g.colind.p, g.diag.p, lu, s.dn_P.p);
-    else
-      hipLaunchKernelGGL(k_ilu_invert, dim3(s.n_blocks), dim3(256), 0, h->stream, s.block_ptr.p, s.dn_off.p, g.rowptr.p, g.colind.p, g.diag.p, lu,
-                         s.dn_P.p);
+    hipLaunchKernelGGL(k_ilu_invert, dim3(s.n_blocks), dim3(256), 0, h->stream, s.block_ptr.p, s.dn_off.p, g.rowptr.p, g.colind.p, g.diag.p, lu,
+                       s.dn_P.p);
   }
 }
 

@@ -165,3 +165,73 @@ def test_schur_cg_persistent_kernel_is_the_one_that_runs():
     dev.close()
     assert table.get("cg_S", {}).get("launches", 0) > 0
     assert table.get("cg_update", {}).get("launches", 0) == 0
+
+
+def test_null_handle_and_unsorted_schur_blocks_are_argument_errors(prob):
+    import ctypes as C
+    import navierstokes_project_nm4pde_amd.nsx as nsx
+    L = nsx.lib()
+    buf = (C.c_double * 4)()
+    for fn in (L.nsx_get_solution, L.nsx_get_solution_ghosted, L.nsx_get_rhs, L.nsx_set_rhs, L.nsx_set_solution):
+        assert fn(None, buf) == -1
+    assert L.nsx_set_ranks(None, 1, None, None) == -1
+    dev = prob.device()
+    ptr = np.asarray(prob.dofs.owned_p_ptr, dtype=np.int32).copy()
+    ptr[1], ptr[2] = ptr[2], ptr[1]                 # first and last entry still right, the middle not ascending
+    if ptr[1] != ptr[2]:
+        with pytest.raises(nsx.NsxError) as e:
+            dev.set_schur_blocks(ptr)
+        assert e.value.code == -1
+    dev.close()
+
+
+def test_two_handles_driven_concurrently_on_one_device():
+    """Two single-GPU handles alive on the same device, each driven by its own host thread.  The persistent kernels (Gram-Schmidt
+    sweep, Schur CG) need all their workgroups resident; when the other handle's kernels hold compute units a grid may not be,
+    the bounded waits then end the kernel without touching its vectors and the solve continues on the launch-per-operation
+    path.  Either way both solves must end at the single-handle answer."""
+    import threading
+    p = Problem("cylinder", 3, 2, n_sub=24, ordering="colour")
+    ref_dev, _ = _assembled(p)
+    ref = ref_dev.solve_time_step(0, tol_abs=1e-10, inner_rtol=1e-8)
+    x_ref = ref_dev.solution_owned.copy()
+    ref_dev.close()
+    devs = [_assembled(p)[0] for _ in range(2)]
+    out, errs = [None, None], []
+
+    def run(k):
+        try:
+            st = devs[k].solve_time_step(0, tol_abs=1e-10, inner_rtol=1e-8)
+            out[k] = (st, devs[k].solution_owned.copy())
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    threads = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for d in devs:
+        d.close()
+    assert not errs, errs
+    for st, x in out:
+        assert st["status"] == 0
+        assert abs(st["outer_iterations"] - ref["outer_iterations"]) <= 2
+        assert np.abs(x - x_ref).max() < 1e-7 * np.abs(x_ref).max()
+
+
+def test_cooperative_launch_of_the_gram_schmidt_sweep(prob):
+    """NSX_MGS_COOP=1: the sweep goes through hipLaunchCooperativeKernel (launch-time size check); same results."""
+    res = []
+    for flag in ("0", "1"):
+        os.environ["NSX_MGS_COOP"] = flag
+        try:
+            dev, _ = _assembled(prob)
+            st = dev.solve_time_step(0, tol_abs=1e-10, inner_rtol=1e-8)
+            res.append((st, dev.solution_owned.copy()))
+            dev.close()
+        finally:
+            os.environ.pop("NSX_MGS_COOP", None)
+    (s0, x0), (s1, x1) = res
+    assert s0["outer_iterations"] == s1["outer_iterations"] and s0["inner_F_iterations"] == s1["inner_F_iterations"]
+    assert np.abs(x0 - x1).max() < 1e-12 * np.abs(x0).max()
