@@ -68,33 +68,58 @@ __global__ void k_pack(int n, const int32_t *__restrict__ idx, const double *__r
   for (int c = 0; c < NC; ++c) buf[(size_t)k * NC + c] = x[(size_t)i * NC + c];
 }
 
-// refresh the ghost part of x (node-major, ncomp values per node) from the owners
-void comm_halo(nsx_handle *h, HaloPlan &p, double *x, int ncomp) {
+static void launch_pack(nsx_handle *h, HaloPlan &p, const double *x, int ncomp, int n_send, hipStream_t st) {
+  if (!n_send) return;
+  if (ncomp == 1) hipLaunchKernelGGL((k_pack<1>), dim3(cdiv(n_send, 256)), dim3(256), 0, st, n_send, p.send_idx.p, x, p.sendbuf.p);
+  else if (ncomp == 2) hipLaunchKernelGGL((k_pack<2>), dim3(cdiv(n_send, 256)), dim3(256), 0, st, n_send, p.send_idx.p, x, p.sendbuf.p);
+  else hipLaunchKernelGGL((k_pack<3>), dim3(cdiv(n_send, 256)), dim3(256), 0, st, n_send, p.send_idx.p, x, p.sendbuf.p);
+}
+
+// Refresh the ghost part of x (node-major, ncomp values per node) from the owners — the Epetra_Import of every vmult.
+// begin: on the communication stream, behind everything the compute stream holds so far: pack, then (RCCL) the grouped
+// send / receive straight into the ghost region, or (callbacks) the copy of the packed values to the host.
+void comm_halo_begin(nsx_handle *h, HaloPlan &p, double *x, int ncomp) {
   Comm *c = h->comm;
   const int nn = (int)p.nbr.size();
   if (nn == 0) return;
   if (!c || c->world == 1) NSX_THROW(NSX_ERR_COMM, "distributed mesh set but no communicator: call nsx_comm_init* first");
-  const int n_send = p.send_ptr[nn];
-  LaunchScope ls(h, ncomp == 1 ? "halo_p" : "halo_u", 16.0 * (n_send + p.recv_ptr[nn]) * ncomp);
-  if (n_send) {
-    if (ncomp == 1) hipLaunchKernelGGL((k_pack<1>), dim3(cdiv(n_send, 256)), dim3(256), 0, h->stream, n_send, p.send_idx.p, x, p.sendbuf.p);
-    else if (ncomp == 2) hipLaunchKernelGGL((k_pack<2>), dim3(cdiv(n_send, 256)), dim3(256), 0, h->stream, n_send, p.send_idx.p, x, p.sendbuf.p);
-    else hipLaunchKernelGGL((k_pack<3>), dim3(cdiv(n_send, 256)), dim3(256), 0, h->stream, n_send, p.send_idx.p, x, p.sendbuf.p);
+  if (!h->comm_stream) {
+    HIP_CHECK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+    HIP_CHECK(hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
   }
+  if (!p.ev_done) HIP_CHECK(hipEventCreateWithFlags(&p.ev_done, hipEventDisableTiming));
+  const int n_send = p.send_ptr[nn];
+  HIP_CHECK(hipEventRecord(h->ev_ready, h->stream));
+  HIP_CHECK(hipStreamWaitEvent(h->comm_stream, h->ev_ready, 0));
+  launch_pack(h, p, x, ncomp, n_send, h->comm_stream);
   double *ghost = x + (size_t)p.n_own * ncomp;
   if (c->comm) {
     NCCL_CHECK(ncclGroupStart());
     for (int k = 0; k < nn; ++k) {
       const size_t ns = (size_t)(p.send_ptr[k + 1] - p.send_ptr[k]) * ncomp, nr = (size_t)(p.recv_ptr[k + 1] - p.recv_ptr[k]) * ncomp;
-      if (ns) NCCL_CHECK(ncclSend(p.sendbuf.p + (size_t)p.send_ptr[k] * ncomp, ns, ncclDouble, p.nbr[k], c->comm, h->stream));
-      if (nr) NCCL_CHECK(ncclRecv(ghost + (size_t)p.recv_ptr[k] * ncomp, nr, ncclDouble, p.nbr[k], c->comm, h->stream));
+      if (ns) NCCL_CHECK(ncclSend(p.sendbuf.p + (size_t)p.send_ptr[k] * ncomp, ns, ncclDouble, p.nbr[k], c->comm, h->comm_stream));
+      if (nr) NCCL_CHECK(ncclRecv(ghost + (size_t)p.recv_ptr[k] * ncomp, nr, ncclDouble, p.nbr[k], c->comm, h->comm_stream));
     }
     NCCL_CHECK(ncclGroupEnd());
+    HIP_CHECK(hipEventRecord(p.ev_done, h->comm_stream));
   } else {
     p.h_send.resize((size_t)n_send * ncomp);
     p.h_recv.resize((size_t)p.recv_ptr[nn] * ncomp);
-    if (n_send) HIP_CHECK(hipMemcpyAsync(p.h_send.data(), p.sendbuf.p, p.h_send.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_CHECK(hipStreamSynchronize(h->stream));
+    if (n_send) HIP_CHECK(hipMemcpyAsync(p.h_send.data(), p.sendbuf.p, p.h_send.size() * sizeof(double), hipMemcpyDeviceToHost, h->comm_stream));
+    p.in_flight = true;
+  }
+}
+
+// finish: the compute stream waits for the ghosts.  Callback backend: the host exchange happens here, while the kernels
+// enqueued since comm_halo_begin (the interior rows) run on the device.
+void comm_halo_finish(nsx_handle *h, HaloPlan &p, double *x, int ncomp) {
+  Comm *c = h->comm;
+  const int nn = (int)p.nbr.size();
+  if (nn == 0) return;
+  if (!c->comm) {
+    if (!p.in_flight) NSX_THROW(NSX_ERR_COMM, "internal: comm_halo_finish without comm_halo_begin");
+    p.in_flight = false;
+    HIP_CHECK(hipStreamSynchronize(h->comm_stream));
     std::vector<const double *> sp(nn);
     std::vector<double *> rp(nn);
     std::vector<int> sc(nn), rc(nn), ranks(nn);
@@ -106,12 +131,32 @@ void comm_halo(nsx_handle *h, HaloPlan &p, double *x, int ncomp) {
       rc[k] = (p.recv_ptr[k + 1] - p.recv_ptr[k]) * ncomp;
     }
     if (c->exchange(c->ctx, nn, ranks.data(), sp.data(), sc.data(), rp.data(), rc.data())) NSX_THROW(NSX_ERR_COMM, "exchange callback failed");
-    if (!p.h_recv.empty()) HIP_CHECK(hipMemcpyAsync(ghost, p.h_recv.data(), p.h_recv.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIP_CHECK(hipStreamSynchronize(h->stream));
+    double *ghost = x + (size_t)p.n_own * ncomp;
+    if (!p.h_recv.empty()) HIP_CHECK(hipMemcpyAsync(ghost, p.h_recv.data(), p.h_recv.size() * sizeof(double), hipMemcpyHostToDevice, h->comm_stream));
+    HIP_CHECK(hipStreamSynchronize(h->comm_stream));  // the staging vector is reused by the next exchange
+    HIP_CHECK(hipEventRecord(p.ev_done, h->comm_stream));
   }
+  HIP_CHECK(hipStreamWaitEvent(h->stream, p.ev_done, 0));
+}
+
+void comm_halo(nsx_handle *h, HaloPlan &p, double *x, int ncomp) {
+  if (p.nbr.empty()) return;
+  const int nn = (int)p.nbr.size();
+  LaunchScope ls(h, ncomp == 1 ? "halo_p" : "halo_u", 16.0 * (p.send_ptr[nn] + p.recv_ptr[nn]) * ncomp);
+  comm_halo_begin(h, p, x, ncomp);
+  comm_halo_finish(h, p, x, ncomp);
 }
 
 void comm_destroy(nsx_handle *h) {
+  for (HaloPlan *p : {&h->haloU, &h->haloP})
+    if (p->ev_done) {
+      (void)hipEventDestroy(p->ev_done);
+      p->ev_done = nullptr;
+    }
+  if (h->ev_ready) (void)hipEventDestroy(h->ev_ready);
+  h->ev_ready = nullptr;
+  if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
+  h->comm_stream = nullptr;
   if (!h->comm) return;
   if (h->comm->comm) (void)ncclCommDestroy(h->comm->comm);
   delete h->comm;

@@ -138,6 +138,15 @@ struct HaloPlan {
   DevBuf<double> sendbuf;
   std::vector<double> h_send, h_recv;       // host staging for the callback backend
   int n_own = 0;                            // ghosts start at node n_own
+  hipEvent_t ev_done = nullptr;             // recorded on the communication stream when the ghosts of the last exchange are in place
+  bool in_flight = false;                   // callback backend: packed and copied out, the host exchange itself still to do
+};
+
+// Rows of a distributed operator that can be computed before the halo of its input arrives (all their columns are owned)
+// and those that cannot (at least one ghost column): the interior rows run while the exchange is in flight.
+struct RowSplit {
+  DevBuf<int32_t> interior, interface;
+  int n_interior = 0, n_interface = 0;
 };
 
 // LDS-staged ("blocked") SpMV schedule on a CSR graph: rows are cut into chunks of R consecutive rows; per chunk the
@@ -188,6 +197,9 @@ struct nsx_handle {
   int rank = 0, world = 1, goff_u = 0, goff_p = 0, n_u_glob = 0, n_p_glob = 0;  // global numbering of this rank's range
   std::vector<int32_t> ghost_u, ghost_p;               // global ids of the ghost nodes (sorted)
   nsx::HaloPlan haloU, haloP;
+  nsx::RowSplit splitA, splitVel, splitB, splitG, splitS;  // F alone, F + block(0,1) (the saddle product), block(1,0), block(0,1), S
+  hipStream_t comm_stream = nullptr;                       // halo pack / send / receive run here, beside the compute stream
+  hipEvent_t ev_ready = nullptr;                           // "the input vector is complete" (compute stream -> communication stream)
   bool have_tables = false, have_mesh = false, assembled = false, prec_ready = false;
   std::vector<double> N2_h, dN2_h, N1_h, w_h;
   nsx::DevBuf<double> tab_N2, tab_dN2, tab_N1, tab_w, tab_N2T, tab_dN2T;  // T: [a][q] / [b][q][k]
@@ -377,6 +389,11 @@ void solve_time_step(nsx_handle *h, int type, double tol, double inner_rtol, int
 void comm_allreduce_scalars(nsx_handle *h, int slot0, int count);
 void comm_allreduce_partials(nsx_handle *h, double *partials, int count);  // in place, same count on every rank
 void comm_halo(nsx_handle *h, HaloPlan &plan, double *x, int ncomp);
+// the same exchange in two halves: begin enqueues pack + send/receive on the communication stream (after everything the
+// compute stream holds so far), finish makes the compute stream wait for the ghosts; kernels launched in between overlap it
+void comm_halo_begin(nsx_handle *h, HaloPlan &plan, double *x, int ncomp);
+void comm_halo_finish(nsx_handle *h, HaloPlan &plan, double *x, int ncomp);
+void build_row_splits(nsx_handle *h);
 inline void comm_halo_u(nsx_handle *h, const double *x) { if (h->dist) comm_halo(h, h->haloU, const_cast<double *>(x), h->dim); }
 inline void comm_halo_p(nsx_handle *h, const double *x) { if (h->dist) comm_halo(h, h->haloP, const_cast<double *>(x), 1); }
 void comm_destroy(nsx_handle *h);

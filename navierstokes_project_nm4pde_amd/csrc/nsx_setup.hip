@@ -703,6 +703,7 @@ void setup_mesh(nsx_handle *h, int n_cells, int n_cells1, const double *cell_coo
     v->zero(h->stream);
   }
   build_schur_graph(h);
+  build_row_splits(h);
   default_ranks(h);
   refresh_rank_products(h);
   HIP_CHECK(hipStreamSynchronize(h->stream));

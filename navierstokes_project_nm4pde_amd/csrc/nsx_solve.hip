@@ -68,8 +68,10 @@ enum { S_H = 8 /* 8..8+N_TMP */, S_NRM = 40, S_H2 = 41 /* re-orthogonalisation c
 // zero_new: a freshly created Epetra vector is zero.  That only matters when the preconditioner READS its destination
 // (aSIMPLE takes it as the initial guess of its inner solve, Prec.hpp:271), i.e. for the outer solve; the inner solves'
 // operators (SpMV, ILU) overwrite every owned entry, so their temporaries are handed out as they come from the pool.
+// x_is_zero: the caller has just zeroed x (Prec.hpp:401): the residual b - A x of the first cycle is b without touching the matrix
+// (deal.II forms it through vmult + sadd; -1 * (A 0) + b gives the same numbers).
 static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b, const Op &P, Span n, int len, double tol, int maxiter,
-                         bool zero_new = false) {
+                         bool zero_new = false, bool x_is_zero = false) {
   SolveResult res{1, 0, 0.0};
   std::vector<std::unique_ptr<Tmp>> tmp(N_TMP);
   auto vec = [&](int i) -> double * {
@@ -87,8 +89,13 @@ static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b,
   bool ahead = false;
   do {
     ahead = false;
-    A(p, x);
-    v_sadd(h, n, p, -1., 1., b);
+    if (x_is_zero) {
+      v_copy(h, n.n, p, b);  // inner solves only: plain vectors without a ghost gap
+      x_is_zero = false;
+    } else {
+      A(p, x);
+      v_sadd(h, n, p, -1., 1., b);
+    }
     P(v, p);
     v_dot(h, n, v, v, S_NRM);
     double rho = std::sqrt(read_scalar(h, S_NRM));
@@ -301,7 +308,7 @@ void prec_vmult(nsx_handle *h, int type, double tol, int maxit, double *dst, con
     spmv_G(h, dst_p, tmp2.p(), false);                                                        // :398
     v_zero(h, n_u, res.p());                                                                  // :401
     v_copy(h, n_u, dst_u, yu.p());                                                            // :402
-    count(st, true, gmres(h, Fm, res.p(), tmp2.p(), PF, n_u, len_u, tol * norm2(h, n_u, tmp2.p()), maxit));  // :403-405
+    count(st, true, gmres(h, Fm, res.p(), tmp2.p(), PF, n_u, len_u, tol * norm2(h, n_u, tmp2.p()), maxit, false, true));  // :403-405
     v_sadd(h, n_u, dst_u, -1., 1., res.p());  // dst.block(0).sadd(-1,res): dst = -dst + res            :406
   } else if (type == NSX_PREC_SIMPLE) {  // Prec.hpp:151-205
     Tmp sol1_u(h, len_u), sol1_p(h, len_p), temp_1(h, len_p), tmp(h, len_u);

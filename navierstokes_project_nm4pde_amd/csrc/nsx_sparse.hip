@@ -37,13 +37,15 @@ __global__ __launch_bounds__(256) void k_spmv_vel(int n_rows, const int32_t *__r
                                                   const double *__restrict__ av, const double *__restrict__ x,
                                                   const int32_t *__restrict__ grp, const int32_t *__restrict__ gci,
                                                   const double *__restrict__ gv, const double *__restrict__ xp,
-                                                  double *__restrict__ y) {
+                                                  double *__restrict__ y, const int32_t *__restrict__ rows) {
+  // rows: optional list of the rows to compute (n_rows of them): interior / interface split of a distributed product
   // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs, so give XCD k the k-th contiguous eighth of the
   // rows: the x entries a row gathers are then shared inside one 4-MiB L2 instead of being fetched into all eight
   // (grid is a multiple of 8; speed only, any placement is correct).
   const int bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  const int row = (bid * 256 + threadIdx.x) / W, lane = threadIdx.x % W;
-  if (row >= n_rows) return;  // whole groups exit together
+  const int slot = (bid * 256 + threadIdx.x) / W, lane = threadIdx.x % W;
+  if (slot >= n_rows) return;  // whole groups exit together
+  const int row = rows ? rows[slot] : slot;
   double acc[DIM];
 #pragma unroll
   for (int c = 0; c < DIM; ++c) acc[c] = 0.0;
@@ -74,9 +76,10 @@ __global__ __launch_bounds__(256) void k_spmv_vel(int n_rows, const int32_t *__r
 template <int DIM, int W>
 __global__ __launch_bounds__(256) void k_spmv_G(int n_rows, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
                                                 const double *__restrict__ gv, const double *__restrict__ xp,
-                                                double *__restrict__ y, int accumulate) {
-  const int row = (blockIdx.x * 256 + threadIdx.x) / W, lane = threadIdx.x % W;
-  if (row >= n_rows) return;
+                                                double *__restrict__ y, int accumulate, const int32_t *__restrict__ rows) {
+  const int slot = (blockIdx.x * 256 + threadIdx.x) / W, lane = threadIdx.x % W;
+  if (slot >= n_rows) return;
+  const int row = rows ? rows[slot] : slot;
   double acc[DIM];
 #pragma unroll
   for (int c = 0; c < DIM; ++c) acc[c] = 0.0;
@@ -101,9 +104,10 @@ __global__ __launch_bounds__(256) void k_spmv_G(int n_rows, const int32_t *__res
 template <int DIM, int W>
 __global__ __launch_bounds__(256) void k_spmv_B(int n_rows, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
                                                 const double *__restrict__ bv, const double *__restrict__ xu,
-                                                double *__restrict__ y) {
-  const int row = (blockIdx.x * 256 + threadIdx.x) / W, lane = threadIdx.x % W;
-  if (row >= n_rows) return;
+                                                double *__restrict__ y, const int32_t *__restrict__ rows) {
+  const int slot = (blockIdx.x * 256 + threadIdx.x) / W, lane = threadIdx.x % W;
+  if (slot >= n_rows) return;
+  const int row = rows ? rows[slot] : slot;
   double acc = 0.0;
   const int e = rp[row + 1];
   for (int p = rp[row] + lane; p < e; p += W) {
@@ -118,9 +122,10 @@ __global__ __launch_bounds__(256) void k_spmv_B(int n_rows, const int32_t *__res
 template <int W>
 __global__ __launch_bounds__(256) void k_spmv_csr(int n_rows, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
                                                   const double *__restrict__ v, const double *__restrict__ x,
-                                                  double *__restrict__ y) {
-  const int row = (blockIdx.x * 256 + threadIdx.x) / W, lane = threadIdx.x % W;
-  if (row >= n_rows) return;
+                                                  double *__restrict__ y, const int32_t *__restrict__ rows) {
+  const int slot = (blockIdx.x * 256 + threadIdx.x) / W, lane = threadIdx.x % W;
+  if (slot >= n_rows) return;
+  const int row = rows ? rows[slot] : slot;
   double acc = 0.0;
   const int e = rp[row + 1];
   for (int p = rp[row] + lane; p < e; p += W) acc += v[p] * x[ci[p]];
@@ -213,8 +218,56 @@ static double bytes_vel(nsx_handle *h, bool with_g) {
   return b;
 }
 
+// ---- launches (rows == nullptr: all n rows)
+static void launch_vel(nsx_handle *h, bool with_g, const double *vals, const double *x, const double *xp, double *y, const int32_t *rows, int n) {
+  if (n <= 0) return;
+  static const int Wsel = getenv("NSX_SPMV_W") ? atoi(getenv("NSX_SPMV_W")) : 16;
+#define NSX_SPMV(D, W_, G_)                                                                                                            \
+  hipLaunchKernelGGL((k_spmv_vel<D, W_, G_>), dim3((cdiv((int64_t)n * W_, 256) + 7) & ~7), dim3(256), 0, h->stream, n, h->gA.rowptr.p, \
+                     h->gA.colind.p, vals, x, h->gG.rowptr.p, h->gG.colind.p, h->vG.p, xp, y, rows)
+  if (with_g) {
+    if (h->dim == 2) NSX_SPMV(2, 16, true); else NSX_SPMV(3, 16, true);
+  } else if (h->dim == 2) {
+    if (Wsel == 8) NSX_SPMV(2, 8, false); else if (Wsel == 32) NSX_SPMV(2, 32, false); else NSX_SPMV(2, 16, false);
+  } else {
+    if (Wsel == 8) NSX_SPMV(3, 8, false); else if (Wsel == 32) NSX_SPMV(3, 32, false); else NSX_SPMV(3, 16, false);
+  }
+#undef NSX_SPMV
+}
+static void launch_B(nsx_handle *h, const double *xu, double *yp, const int32_t *rows, int n) {
+  if (n <= 0) return;
+  if (h->dim == 2)
+    hipLaunchKernelGGL((k_spmv_B<2, 32>), dim3(cdiv((int64_t)n * 32, 256)), dim3(256), 0, h->stream, n, h->gB.rowptr.p, h->gB.colind.p, h->vB.p, xu, yp, rows);
+  else
+    hipLaunchKernelGGL((k_spmv_B<3, 64>), dim3(cdiv((int64_t)n * 64, 256)), dim3(256), 0, h->stream, n, h->gB.rowptr.p, h->gB.colind.p, h->vB.p, xu, yp, rows);
+}
+static void launch_G(nsx_handle *h, const double *xp, double *yu, bool accumulate, const int32_t *rows, int n) {
+  if (n <= 0) return;
+  const int W = 8, grid = cdiv((int64_t)n * W, 256);
+  if (h->dim == 2)
+    hipLaunchKernelGGL((k_spmv_G<2, W>), dim3(grid), dim3(256), 0, h->stream, n, h->gG.rowptr.p, h->gG.colind.p, h->vG.p, xp, yu, (int)accumulate, rows);
+  else
+    hipLaunchKernelGGL((k_spmv_G<3, W>), dim3(grid), dim3(256), 0, h->stream, n, h->gG.rowptr.p, h->gG.colind.p, h->vG.p, xp, yu, (int)accumulate, rows);
+}
+static void launch_S(nsx_handle *h, const double *x, double *y, const int32_t *rows, int n) {
+  if (n <= 0) return;
+  const int W = 32;
+  hipLaunchKernelGGL((k_spmv_csr<W>), dim3(cdiv((int64_t)n * W, 256)), dim3(256), 0, h->stream, n, h->gS.rowptr.p, h->gS.colind.p, h->vSchur.p, x, y, rows);
+}
+
+// Distributed products: the rows whose columns are all owned are computed while the ghosts of the input are still on
+// their way (second stream, comm_halo_begin / finish); the rows on the partition interface follow once they have arrived.
+// This is the Epetra_Import + local multiply of every vmult with the import hidden behind the interior rows.
 void spmv_F(nsx_handle *h, const double *vals, const double *x, double *y) {
-  comm_halo_u(h, x);
+  if (h->dist) {
+    double *xx = const_cast<double *>(x);
+    LaunchScope ls(h, "spmv_F", bytes_vel(h, false));
+    comm_halo_begin(h, h->haloU, xx, h->dim);
+    launch_vel(h, false, vals, x, nullptr, y, h->splitA.interior.p, h->splitA.n_interior);
+    comm_halo_finish(h, h->haloU, xx, h->dim);
+    launch_vel(h, false, vals, x, nullptr, y, h->splitA.interface.p, h->splitA.n_interface);
+    return;
+  }
   LaunchScope ls(h, "spmv_F", bytes_vel(h, false));
   static const bool blocked = !(getenv("NSX_SPMV_BLOCKED") && atoi(getenv("NSX_SPMV_BLOCKED")) == 0);
   if (blocked && h->blkA.n_chunks > 0) {
@@ -231,68 +284,99 @@ void spmv_F(nsx_handle *h, const double *vals, const double *x, double *y) {
       return;
     }
   }
-  static const int Wsel = getenv("NSX_SPMV_W") ? atoi(getenv("NSX_SPMV_W")) : 16;
-#define NSX_SPMV(D, W_)                                                                                                          \
-  hipLaunchKernelGGL((k_spmv_vel<D, W_, false>), dim3((cdiv((int64_t)h->N2 * W_, 256) + 7) & ~7), dim3(256), 0, h->stream, h->N2, \
-                     h->gA.rowptr.p, h->gA.colind.p, vals, x, nullptr, nullptr, nullptr, nullptr, y)
-  if (h->dim == 2) {
-    if (Wsel == 8) NSX_SPMV(2, 8); else if (Wsel == 32) NSX_SPMV(2, 32); else NSX_SPMV(2, 16);
-  } else {
-    if (Wsel == 8) NSX_SPMV(3, 8); else if (Wsel == 32) NSX_SPMV(3, 32); else NSX_SPMV(3, 16);
-  }
-#undef NSX_SPMV
+  launch_vel(h, false, vals, x, nullptr, y, nullptr, h->N2);
 }
 
-static void spmv_B_nohalo(nsx_handle *h, const double *xu, double *yp);
+static double bytes_B(nsx_handle *h) { return (4.0 + 8.0 * h->dim) * h->gB.nnz() + 12.0 * h->NP + 8.0 * h->dim * h->N2; }
 void spmv_B(nsx_handle *h, const double *xu, double *yp) {
-  comm_halo_u(h, xu);
-  spmv_B_nohalo(h, xu, yp);
-}
-static void spmv_B_nohalo(nsx_handle *h, const double *xu, double *yp) {
-  LaunchScope ls(h, "spmv_B", (4.0 + 8.0 * h->dim) * h->gB.nnz() + 12.0 * h->NP + 8.0 * h->dim * h->N2);
-  const int W = 64, grid = cdiv((int64_t)h->NP * W, 256);
-  if (h->dim == 2)
-    hipLaunchKernelGGL((k_spmv_B<2, 32>), dim3(cdiv((int64_t)h->NP * 32, 256)), dim3(256), 0, h->stream, h->NP, h->gB.rowptr.p,
-                       h->gB.colind.p, h->vB.p, xu, yp);
-  else
-    hipLaunchKernelGGL((k_spmv_B<3, W>), dim3(grid), dim3(256), 0, h->stream, h->NP, h->gB.rowptr.p, h->gB.colind.p, h->vB.p, xu, yp);
+  LaunchScope ls(h, "spmv_B", bytes_B(h));
+  if (h->dist) {
+    double *xx = const_cast<double *>(xu);
+    comm_halo_begin(h, h->haloU, xx, h->dim);
+    launch_B(h, xu, yp, h->splitB.interior.p, h->splitB.n_interior);
+    comm_halo_finish(h, h->haloU, xx, h->dim);
+    launch_B(h, xu, yp, h->splitB.interface.p, h->splitB.n_interface);
+    return;
+  }
+  launch_B(h, xu, yp, nullptr, h->NP);
 }
 
 void spmv_G(nsx_handle *h, const double *xp, double *yu, bool accumulate) {
-  comm_halo_p(h, xp);
   LaunchScope ls(h, "spmv_G", (4.0 + 8.0 * h->dim) * h->gG.nnz() + (double)h->N2 * (4 + 8.0 * h->dim) + 8.0 * h->NP);
-  const int W = 8, grid = cdiv((int64_t)h->N2 * W, 256);
-  if (h->dim == 2)
-    hipLaunchKernelGGL((k_spmv_G<2, W>), dim3(grid), dim3(256), 0, h->stream, h->N2, h->gG.rowptr.p, h->gG.colind.p, h->vG.p, xp, yu,
-                       (int)accumulate);
-  else
-    hipLaunchKernelGGL((k_spmv_G<3, W>), dim3(grid), dim3(256), 0, h->stream, h->N2, h->gG.rowptr.p, h->gG.colind.p, h->vG.p, xp, yu,
-                       (int)accumulate);
+  if (h->dist) {
+    double *xx = const_cast<double *>(xp);
+    comm_halo_begin(h, h->haloP, xx, 1);
+    launch_G(h, xp, yu, accumulate, h->splitG.interior.p, h->splitG.n_interior);
+    comm_halo_finish(h, h->haloP, xx, 1);
+    launch_G(h, xp, yu, accumulate, h->splitG.interface.p, h->splitG.n_interface);
+    return;
+  }
+  launch_G(h, xp, yu, accumulate, nullptr, h->N2);
 }
 
 // BlockSparseMatrix::vmult: y_u = F x_u + block(0,1) x_p ; y_p = block(1,0) x_u  (block (1,1) has an empty pattern)
 void spmv_saddle(nsx_handle *h, const double *x, double *y) {
-  comm_halo_u(h, x);
-  comm_halo_p(h, x + h->off_p);
+  double *xx = const_cast<double *>(x);
+  if (h->dist) {
+    comm_halo_begin(h, h->haloU, xx, h->dim);
+    comm_halo_begin(h, h->haloP, xx + h->off_p, 1);
+  }
   {
     LaunchScope ls(h, "spmv_saddle_u", bytes_vel(h, true));
-    const int W = 16, grid = (cdiv((int64_t)h->N2 * W, 256) + 7) & ~7;
-    if (h->dim == 2)
-      hipLaunchKernelGGL((k_spmv_vel<2, W, true>), dim3(grid), dim3(256), 0, h->stream, h->N2, h->gA.rowptr.p, h->gA.colind.p, h->vF.p, x,
-                         h->gG.rowptr.p, h->gG.colind.p, h->vG.p, x + h->off_p, y);
-    else
-      hipLaunchKernelGGL((k_spmv_vel<3, W, true>), dim3(grid), dim3(256), 0, h->stream, h->N2, h->gA.rowptr.p, h->gA.colind.p, h->vF.p, x,
-                         h->gG.rowptr.p, h->gG.colind.p, h->vG.p, x + h->off_p, y);
+    if (h->dist) launch_vel(h, true, h->vF.p, x, x + h->off_p, y, h->splitVel.interior.p, h->splitVel.n_interior);
+    else launch_vel(h, true, h->vF.p, x, x + h->off_p, y, nullptr, h->N2);
   }
-  spmv_B_nohalo(h, x, y + h->off_p);
+  {
+    LaunchScope ls(h, "spmv_B", bytes_B(h));
+    if (h->dist) launch_B(h, x, y + h->off_p, h->splitB.interior.p, h->splitB.n_interior);
+    else launch_B(h, x, y + h->off_p, nullptr, h->NP);
+  }
+  if (h->dist) {
+    comm_halo_finish(h, h->haloU, xx, h->dim);
+    comm_halo_finish(h, h->haloP, xx + h->off_p, 1);
+    launch_vel(h, true, h->vF.p, x, x + h->off_p, y, h->splitVel.interface.p, h->splitVel.n_interface);
+    launch_B(h, x, y + h->off_p, h->splitB.interface.p, h->splitB.n_interface);
+  }
 }
 
 void spmv_S(nsx_handle *h, const double *x, double *y) {
-  comm_halo_p(h, x);
   LaunchScope ls(h, "spmv_S", 12.0 * h->gS.nnz() + 20.0 * h->NP);
-  const int W = 32;
-  hipLaunchKernelGGL((k_spmv_csr<W>), dim3(cdiv((int64_t)h->NP * W, 256)), dim3(256), 0, h->stream, h->NP, h->gS.rowptr.p,
-                     h->gS.colind.p, h->vSchur.p, x, y);
+  if (h->dist) {
+    double *xx = const_cast<double *>(x);
+    comm_halo_begin(h, h->haloP, xx, 1);
+    launch_S(h, x, y, h->splitS.interior.p, h->splitS.n_interior);
+    comm_halo_finish(h, h->haloP, xx, 1);
+    launch_S(h, x, y, h->splitS.interface.p, h->splitS.n_interface);
+    return;
+  }
+  launch_S(h, x, y, nullptr, h->NP);
+}
+
+// interior / interface rows of the distributed operators (owned rows; a column >= the owned count is a ghost)
+static void split_rows(nsx_handle *h, RowSplit &sp, int n_rows, const Csr &a, int own_a, const Csr *b, int own_b) {
+  std::vector<int32_t> in, out;
+  for (int i = 0; i < n_rows; ++i) {
+    bool ghost = false;
+    for (int k = a.rowptr[i]; k < a.rowptr[i + 1] && !ghost; ++k) ghost = a.colind[k] >= own_a;
+    if (b)
+      for (int k = b->rowptr[i]; k < b->rowptr[i + 1] && !ghost; ++k) ghost = b->colind[k] >= own_b;
+    (ghost ? out : in).push_back(i);
+  }
+  sp.n_interior = (int)in.size();
+  sp.n_interface = (int)out.size();
+  sp.interior.upload(in, h->stream);
+  sp.interface.upload(out, h->stream);
+}
+void build_row_splits(nsx_handle *h) {
+  if (!h->dist) return;
+  split_rows(h, h->splitA, h->N2, h->gA.host, h->N2, nullptr, 0);
+  split_rows(h, h->splitVel, h->N2, h->gA.host, h->N2, &h->gG.host, h->NP);
+  split_rows(h, h->splitG, h->N2, h->gG.host, h->NP, nullptr, 0);
+  split_rows(h, h->splitB, h->NP, h->gB.host, h->N2, nullptr, 0);
+  split_rows(h, h->splitS, h->NP, h->gS.host, h->NP, nullptr, 0);
+  if (getenv("NSX_DEBUG"))
+    fprintf(stderr, "[nsx] rank %d: interface rows F %d / %d, block(1,0) %d / %d, S %d / %d\n", h->rank, h->splitA.n_interface, h->N2, h->splitB.n_interface,
+            h->NP, h->splitS.n_interface, h->NP);
 }
 
 // ------------------------------------------------------------------ diagonals
