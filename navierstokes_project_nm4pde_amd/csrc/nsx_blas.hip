@@ -172,9 +172,30 @@ void finalize_slots(nsx_handle *h, int slot0, int count) {
   for (int i = 0; i < count; ++i) h->slot_nb[slot0 + i] = 0;
 }
 
+// Hold back / release the all-reduces of finished reductions (distributed runs).  On release, slots whose partial-sum regions
+// are adjacent go out as one collective.
+void defer_reductions(nsx_handle *h, bool on) {
+  h->defer_red = on;
+  if (on || h->pending_red.empty()) return;
+  std::sort(h->pending_red.begin(), h->pending_red.end());
+  size_t k = 0;
+  while (k < h->pending_red.size()) {
+    size_t e = k + 1;
+    while (e < h->pending_red.size() && h->pending_red[e] == h->pending_red[e - 1] + 1) ++e;
+    const int first = h->pending_red[k], count = (int)(e - k);
+    comm_allreduce_partials(h, h->red_partial.p + (size_t)first * RED_STRIDE, (count - 1) * RED_STRIDE + DIST_RED_BLOCKS);
+    k = e;
+  }
+  h->pending_red.clear();
+}
+
 void after_reduction(nsx_handle *h, int slot, int nb) {
   h->slot_nb[slot] = nb > 1 ? nb : 0;
   if (!h->comm) return;
+  if (h->defer_red && nb == DIST_RED_BLOCKS) {
+    h->pending_red.push_back(slot);
+    return;
+  }
   // global sum needed before anybody consumes the value
   if (nb == DIST_RED_BLOCKS) {
     // all-reduce the partial sums themselves (2 KB instead of 8 B costs the same latency) and let the consumer add

@@ -261,6 +261,8 @@ struct nsx_handle {
   std::vector<std::string> prof_names;
   // ---- comm
   nsx::Comm *comm = nullptr;
+  bool defer_red = false;             // distributed runs: all-reduces of finished reductions are held back ...
+  std::vector<int> pending_red;       // ... for these slots, and merged when released (defer_reductions)
 };
 
 namespace nsx {
@@ -367,6 +369,7 @@ void finalize_slots(nsx_handle *h, int slot0, int count);
 // bookkeeping (and the all-reduce of a distributed run) once the kernel is launched
 double *red_out(nsx_handle *h, int slot, int nb);
 void after_reduction(nsx_handle *h, int slot, int nb);
+void defer_reductions(nsx_handle *h, bool on);  // hold back / release (merged) the all-reduces of a distributed run
 double read_scalar(nsx_handle *h, int slot);
 void read_scalars(nsx_handle *h, int slot0, int count, double *out);
 unsigned long long publish_scalars(nsx_handle *h, int slot0, int count);  // asynchronous half of read_scalars

@@ -62,7 +62,7 @@ static int sc_check(int step, double value, double tol, int maxsteps) {  // Solv
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 constexpr int N_TMP = 30;  // SolverGMRES::AdditionalData::max_n_tmp_vectors
-enum { S_H = 8 /* 8..8+N_TMP */, S_NRM = 40, S_H2 = 41 /* re-orthogonalisation coefficients 41..41+N_TMP */, S_GH = 2, S_DH = 3, S_RES = 4, S_GH2 = 5, S_T = 6 };
+enum { S_H = 8 /* 8..8+N_TMP */, S_NRM = 40, S_H2 = 41 /* re-orthogonalisation coefficients 41..41+N_TMP */, S_DH = 2, S_GH = 3, S_RES = 4, S_GH2 = 5 /* S_RES sits between the two g.h slots: whichever is current, the pair is adjacent */, S_T = 6 };
 
 // SolverGMRES<VectorType>::solve (left preconditioning, default residual).
 // zero_new: a freshly created Epetra vector is zero.  That only matters when the preconditioner READS its destination
@@ -204,12 +204,21 @@ static SolveResult cg(nsx_handle *h, const Op &A, double *x, const double *b, co
       it++;
       A(hv.p(), d.p());
       v_dot(h, n, d.p(), hv.p(), S_DH);
+      // Distributed run: |g|^2 and the g.h of the next iteration are independent sums: their all-reduces are held back and
+      // go out as ONE collective over the two adjacent slots (a latency, not a bandwidth, matter: 8 B or 16 KB cost the same).
+      const bool batch = h->comm != nullptr;
+      if (batch) defer_reductions(h, true);
       cg_update(h, n.n, x, d.p(), g.p(), hv.p(), gh, S_DH, S_RES);  // alpha = gh / (d.h); x += alpha d; g += alpha h; res = |g|
       // The residual travels to the host while the GPU already applies the preconditioner of the NEXT iteration
       // (h = P g and g.h only touch temporaries): the host round trip hides behind that kernel instead of idling the
       // device; the work is wasted once per solve, in the iteration that converges.
-      const unsigned long long seq = publish_scalars(h, S_RES, 1);
+      unsigned long long seq = 0;
+      if (!batch) seq = publish_scalars(h, S_RES, 1);
       apply_P_dot(hv.p(), g.p(), gh_new);
+      if (batch) {
+        defer_reductions(h, false);  // flushes: one all-reduce for S_RES and gh_new
+        seq = publish_scalars(h, S_RES, 1);
+      }
       double res2;
       collect_published(h, seq, S_RES, 1, &res2);
       r = std::sqrt(std::fabs(res2));

@@ -241,3 +241,18 @@ def test_pressure_difference_is_the_p1_interpolant(dim):
     assert abs(diff - pressure_difference(m, d, sol, a, b)) < 1e-12      # the numpy version used by the convergence driver
     diff, found = d.pressure_difference(sol, a, np.array([9.0, 9.0, 9.0][:dim]))
     assert found == 1 and abs(diff - (7.0 + a @ g)) < 1e-12              # a point nobody holds contributes 0 (MPI_MAX of zeros)
+
+
+def test_partition_owned_balances_the_ilu_blocks():
+    """nsxh_mesh_partition_owned: equal numbers of OWNED P2 nodes per subdomain under the lowest-id ownership rule (the ILU(0)
+    block sizes), where the cell-balanced bisection gives the low ids up to twice the mean."""
+    sizes = {}
+    for balance in ("cells", "owned"):
+        m = Mesh.cylinder(3, 2).partition(2, 32, balance=balance)
+        assert set(np.unique(m.subdomain)) == set(range(64))
+        d = DoFs(m)
+        sizes[balance] = np.diff(d.owned_u_ptr)
+        assert sizes[balance].sum() == d.n_u // 3 and sizes[balance].min() > 0
+    assert sizes["owned"].max() < 1.2 * sizes["owned"].mean()
+    assert sizes["cells"].max() > 1.4 * sizes["cells"].mean()
+    assert sizes["owned"].max() < sizes["cells"].max()

@@ -313,3 +313,41 @@ def test_forces_hydrostatic_known_answer(dim):
     o.solution[0:d.n_u:dim] = d.support_points[0:d.n_u:dim, 1]
     drag, lift = o.compute_forces(cells, lf, ftab)
     assert abs(drag) < 1e-12 and abs(lift) < 1e-12
+
+
+def test_threaded_oracle_build_equals_the_serial_restatement():
+    """oracle/liboracle_mt.so (bench.py's all-cores CPU baseline: the same source with -fopenmp) against liboracle.so:
+    same iteration history, solution equal to summation-order rounding."""
+    import oracle
+    from navierstokes_project_nm4pde_amd.problem import InletVelocity, cylinder_boundary_values
+    p = Problem("cylinder", 3, 1, n_sub=4)
+    out = []
+    for threads in (1, 4):
+        o = oracle.Oracle(p.dofs, p.tables, p.nu, p.deltat, threads=threads)
+        assert o.threads == threads
+        inlet = InletVelocity(3)
+        o.assemble(oracle.TEMAM)
+        o.apply_boundary_values(*cylinder_boundary_values(p.dofs, inlet, p.deltat))
+        st1 = o.solve_time_step(oracle.YOSIDA, tol_abs=1e-10, inner_rtol=1e-8)
+        o.assemble_time_step(0)
+        o.apply_boundary_values(*cylinder_boundary_values(p.dofs, inlet, 2 * p.deltat))
+        st2 = o.solve_time_step(oracle.YOSIDA, tol_abs=1e-10, inner_rtol=1e-8)
+        out.append((st1, st2, o.solution_owned.copy(), o.matrix(0, 0).copy()))
+    (a1, a2, xa, Fa), (b1, b2, xb, Fb) = out
+    assert a1["status"] == 0 and b1["status"] == 0 and a2["status"] == 0 and b2["status"] == 0
+    assert rel_err(Fb, Fa) < 1e-13
+    assert abs(a2["outer_iterations"] - b2["outer_iterations"]) <= 1
+    assert rel_err(xb, xa) < 1e-7
+
+
+def test_bench_state_transfer_between_numberings():
+    """bench.py hands the GPU run's state to the CPU baseline, which numbers the same mesh with other ranks / node order."""
+    import bench
+    _, da, _ = bench.build_problem(1, 8, 1, "colour")
+    _, db, _ = bench.build_problem(1, 3, 1, "first_touch")
+    X = da.support_points
+    x = np.sin(3 * X[:, 0]) + 2 * X[:, 1] ** 2 - X[:, 2] + 0.25 * (np.arange(da.n_dofs) % 3) * (np.arange(da.n_dofs) < da.n_u)
+    y = bench.transfer_state(da, x, db)
+    Y = db.support_points
+    expect = np.sin(3 * Y[:, 0]) + 2 * Y[:, 1] ** 2 - Y[:, 2] + 0.25 * (np.arange(db.n_dofs) % 3) * (np.arange(db.n_dofs) < db.n_u)
+    assert np.array_equal(y, expect)
