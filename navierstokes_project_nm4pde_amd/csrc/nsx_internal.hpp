@@ -149,11 +149,12 @@ struct RowSplit {
   int n_interior = 0, n_interface = 0;
 };
 
-// LDS-staged ("blocked") SpMV schedule on a CSR graph: rows are cut into chunks of R consecutive rows; per chunk the
+// LDS-staged ("blocked") SpMV schedule on a CSR graph: rows are cut into chunks of consecutive rows; per chunk the
 // sorted unique column list and, per entry, the 16-bit position of its column in that list.  A workgroup stages the
 // chunk's x entries in LDS once (each x entry is gathered once per chunk instead of once per non-zero).
 struct SpmvBlocked {
-  int R = 0, n_chunks = 0, max_ucols = 0;
+  int n_chunks = 0, max_ucols = 0, max_rows = 0;
+  DevBuf<int32_t> crow;  // [n_chunks+1] row range of every chunk (unions of consecutive rank blocks, or a fixed row count)
   DevBuf<int32_t> cptr, ucols;
   DevBuf<uint16_t> lidx;
   double ucols_total = 0;

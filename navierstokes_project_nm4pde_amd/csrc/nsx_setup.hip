@@ -362,14 +362,15 @@ void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> 
   }
 }
 
-void build_blocked(nsx_handle *h, const Csr &g, int R, SpmvBlocked &b) {
-  b.R = R;
-  b.n_chunks = (g.n_rows + R - 1) / R;
+// chunks = [bounds[c], bounds[c+1])
+void build_blocked(nsx_handle *h, const Csr &g, const std::vector<int32_t> &bounds, SpmvBlocked &b) {
+  b.n_chunks = (int)bounds.size() - 1;
   std::vector<int32_t> cptr((size_t)b.n_chunks + 1, 0), ucols, tmp;
   std::vector<uint16_t> lidx(g.nnz());
-  b.max_ucols = 0;
+  b.max_ucols = b.max_rows = 0;
   for (int c = 0; c < b.n_chunks; ++c) {
-    const int r0 = c * R, r1 = std::min(g.n_rows, r0 + R);
+    const int r0 = bounds[c], r1 = bounds[c + 1];
+    b.max_rows = std::max(b.max_rows, r1 - r0);
     tmp.assign(g.colind.begin() + g.rowptr[r0], g.colind.begin() + g.rowptr[r1]);
     std::sort(tmp.begin(), tmp.end());
     tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
@@ -381,12 +382,46 @@ void build_blocked(nsx_handle *h, const Csr &g, int R, SpmvBlocked &b) {
     b.max_ucols = std::max<int>(b.max_ucols, (int)tmp.size());
   }
   b.ucols_total = (double)ucols.size();
+  b.crow.upload(bounds, h->stream);
   b.cptr.upload(cptr, h->stream);
   b.ucols.upload(ucols, h->stream);
   b.lidx.upload(lidx, h->stream);
   if (getenv("NSX_DEBUG"))
-    fprintf(stderr, "[nsx] blocked spmv: rows %d R %d chunks %d unique cols/chunk avg %.0f max %d (nnz/unique %.1f)\n", g.n_rows, R, b.n_chunks,
-            b.ucols_total / b.n_chunks, b.max_ucols, (double)g.nnz() / b.ucols_total);
+    fprintf(stderr, "[nsx] blocked spmv: rows %d chunks %d (max %d rows) unique cols/chunk avg %.0f max %d (nnz/unique %.1f)\n", g.n_rows, b.n_chunks,
+            b.max_rows, b.ucols_total / std::max(1, b.n_chunks), b.max_ucols, (double)g.nnz() / b.ucols_total);
+}
+
+// Chunk boundaries of the LDS-staged SpMV.  With a rank table the chunks are unions of consecutive rank blocks: a rank's rows
+// are the nodes of one subdomain, so a chunk that ends where a subdomain ends stages far fewer columns (7.9 instead of 5.5
+// non-zeros per staged entry at two ranks per chunk) than one that straddles three subdomains; without one, a fixed row count.
+static std::vector<int32_t> spmv_chunks(nsx_handle *h) {
+  const int n = h->gA.host.n_rows;
+  const int target = getenv("NSX_SPMV_R") ? std::max(16, std::min(448, atoi(getenv("NSX_SPMV_R")))) : 192;
+  std::vector<int32_t> bounds{0};
+  const std::vector<int32_t> &rk = h->rank_u_h;
+  const bool by_rank = !(getenv("NSX_SPMV_BY_RANK") && atoi(getenv("NSX_SPMV_BY_RANK")) == 0) && rk.size() > 2 &&
+                       (double)n / (double)(rk.size() - 1) <= target;
+  if (by_rank) {
+    int start = 0;
+    for (size_t r = 1; r < rk.size(); ++r) {
+      // close the chunk in front of a rank that would take it past the target (a single oversized rank is cut below)
+      if (rk[r] - start > target && rk[r - 1] > start) {
+        bounds.push_back(rk[r - 1]);
+        start = rk[r - 1];
+      }
+    }
+    bounds.push_back(n);
+  } else {
+    for (int r = 128; r < n; r += 128) bounds.push_back(r);
+    bounds.push_back(n);
+  }
+  // no chunk above 448 rows (the kernel's row-pointer buffer)
+  std::vector<int32_t> out{0};
+  for (size_t c = 1; c < bounds.size(); ++c) {
+    while (bounds[c] - out.back() > 448) out.push_back(out.back() + 224);
+    if (bounds[c] > out.back()) out.push_back(bounds[c]);
+  }
+  return out;
 }
 
 void build_schur_graph(nsx_handle *h) {
@@ -445,6 +480,7 @@ static void refresh_rank_products(nsx_handle *h) {
 
 void ensure_schedules(nsx_handle *h) {
   if (!h->sched_dirty) return;
+  if (!h->dist) build_blocked(h, h->gA.host, spmv_chunks(h), h->blkA);
   const int lwF = getenv("NSX_LW_F") ? atoi(getenv("NSX_LW_F")) : 8, lwS = getenv("NSX_LW_S") ? atoi(getenv("NSX_LW_S")) : 32;
   const int bpwF = getenv("NSX_BPW_F") ? atoi(getenv("NSX_BPW_F")) : 1, bpwS = getenv("NSX_BPW_S") ? atoi(getenv("NSX_BPW_S")) : 1;
   const bool wideF = !(getenv("NSX_WIDE") && atoi(getenv("NSX_WIDE")) == 0);
@@ -632,7 +668,6 @@ void setup_mesh(nsx_handle *h, int n_cells, int n_cells1, const double *cell_coo
   h->gPM.host = build_graph(n_cells, np1, c1, h->NP_loc, np1, c1, h->NP_loc);
   truncate_rows(h->gPM.host, h->NP);
   upload_csr(h, h->gA, true);
-  build_blocked(h, h->gA.host, getenv("NSX_SPMV_R") ? std::max(16, std::min(256, atoi(getenv("NSX_SPMV_R")))) : 128, h->blkA);
   upload_csr(h, h->gG, false);
   upload_csr(h, h->gB, false);
   upload_csr(h, h->gPM, true);

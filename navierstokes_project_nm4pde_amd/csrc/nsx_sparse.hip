@@ -137,12 +137,12 @@ __global__ __launch_bounds__(256) void k_spmv_csr(int n_rows, const int32_t *__r
 // The per-non-zero stream is 8 B value + 2 B local column; the 24-B gathers of the plain kernel (10 M per product,
 // bound by the per-CU address rate, not by bytes) become ~1.5 M staged gathers + LDS reads.
 template <int DIM, int W>
-__global__ __launch_bounds__(256) void k_spmv_blocked(int n_rows, int n_chunks, int R, const int32_t *__restrict__ rp, const uint16_t *__restrict__ lidx,
+__global__ __launch_bounds__(256) void k_spmv_blocked(int n_rows, int n_chunks, const int32_t *__restrict__ crow, const int32_t *__restrict__ rp, const uint16_t *__restrict__ lidx,
                                                       const double *__restrict__ av, const int32_t *__restrict__ cptr,
                                                       const int32_t *__restrict__ ucols, const double *__restrict__ x,
                                                       double *__restrict__ y) {
   extern __shared__ double xs[];
-  __shared__ int rps[257];
+  __shared__ int rps[449];
   // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs; XCD k takes the k-th contiguous eighth of the chunks,
   // so the x entries its chunks stage (neighbouring chunks share most of them) stay in ONE 4-MiB L2 instead of being fetched
   // into all eight (x is 8 MB at 1 M DoF: every L2 used to miss on it).  Grid = 8 * ceil(n_chunks / 8); speed only.
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void k_spmv_blocked(int n_rows, int n_chunks, 
   const int chunk = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (chunk >= n_chunks) return;
   const int c0 = cptr[chunk], nu = cptr[chunk + 1] - c0;
-  const int r0 = chunk * R, r1 = min(n_rows, r0 + R);
+  const int r0 = crow[chunk], r1 = crow[chunk + 1];
   for (int t = threadIdx.x; t <= r1 - r0; t += 256) rps[t] = rp[r0 + t];
   for (int t = threadIdx.x; t < nu; t += 256) {
     const double *xj = x + (size_t)ucols[c0 + t] * DIM;
@@ -270,16 +270,16 @@ void spmv_F(nsx_handle *h, const double *vals, const double *x, double *y) {
   }
   LaunchScope ls(h, "spmv_F", bytes_vel(h, false));
   static const bool blocked = !(getenv("NSX_SPMV_BLOCKED") && atoi(getenv("NSX_SPMV_BLOCKED")) == 0);
-  if (blocked && h->blkA.n_chunks > 0) {
+  if (blocked && h->blkA.n_chunks > 0 && h->blkA.max_rows <= 448) {
     const SpmvBlocked &b = h->blkA;
     const size_t shm = (size_t)b.max_ucols * h->dim * sizeof(double);
     if (shm <= 64 * 1024) {
       const int grid = 8 * cdiv(b.n_chunks, 8);
       if (h->dim == 2)
-        hipLaunchKernelGGL((k_spmv_blocked<2, 16>), dim3(grid), dim3(256), shm, h->stream, h->N2, b.n_chunks, b.R, h->gA.rowptr.p, b.lidx.p, vals,
+        hipLaunchKernelGGL((k_spmv_blocked<2, 16>), dim3(grid), dim3(256), shm, h->stream, h->N2, b.n_chunks, b.crow.p, h->gA.rowptr.p, b.lidx.p, vals,
                            b.cptr.p, b.ucols.p, x, y);
       else
-        hipLaunchKernelGGL((k_spmv_blocked<3, 16>), dim3(grid), dim3(256), shm, h->stream, h->N2, b.n_chunks, b.R, h->gA.rowptr.p, b.lidx.p, vals,
+        hipLaunchKernelGGL((k_spmv_blocked<3, 16>), dim3(grid), dim3(256), shm, h->stream, h->N2, b.n_chunks, b.crow.p, h->gA.rowptr.p, b.lidx.p, vals,
                            b.cptr.p, b.ucols.p, x, y);
       return;
     }
