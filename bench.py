@@ -284,7 +284,7 @@ def main():
     ap.add_argument("--schur-blocks", type=int, default=512, help="ILU(0) blocks of the Schur matrix")
     ap.add_argument("--ordering", choices=("colour", "first_touch"), default="colour",
                     help="velocity node order inside a virtual rank (include/nsx_host.h: nsxh_distribute_dofs_ordered)")
-    ap.add_argument("--balance", choices=("cells", "owned"), default="cells",
+    ap.add_argument("--balance", choices=("cells", "owned"), default="owned",
                     help="what the partitioner equalises over the virtual ranks: cells (METIS-like) or owned P2 nodes = ILU block sizes")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-only", action="store_true", help="only the cpu_baseline leg (after a short GPU run that provides its state)")
@@ -391,8 +391,10 @@ def main():
         "time_steps_per_s_of_this_mesh": raw,
         "dtype": "f64", "data": "synthetic (block-structured tetrahedral cylinder mesh, u0 = 0, reference inlet profile)",
         "config": {"workload": "3D flow-past-cylinder, P2/P1 (reference FE_SimplexP), %d DoF, %d cells, dt=2e-4, nu=1e-3, u_m=9, "
-                               "GMRES(1e-4 abs)+Yosida(inner 1e-2), ILU(0) per rank with %d ranks (Schur: %d blocks), %s node order inside a rank"
-                               % (dofs.n_dofs, dofs.n_cells, args.ranks * world, args.schur_blocks * world, args.ordering),
+                               "GMRES(1e-4 abs)+Yosida(inner 1e-2), ILU(0) per rank with %d ranks (bisection balanced on %s; Schur: %d blocks), "
+                               "%s node order inside a rank"
+                               % (dofs.n_dofs, dofs.n_cells, args.ranks * world, "owned nodes" if args.balance == "owned" else "cells",
+                                  args.schur_blocks * world, args.ordering),
                    "n_dofs": dofs.n_dofs, "n_cells": dofs.n_cells,
                    "parallelism": "mesh partitioned over %d GPU(s): RCCL ghost exchange + dot-product all-reduce" % world},
         "gmres_outer_iters_per_step": outer / n,

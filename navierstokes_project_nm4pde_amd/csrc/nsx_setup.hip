@@ -392,11 +392,13 @@ void build_blocked(nsx_handle *h, const Csr &g, const std::vector<int32_t> &boun
 }
 
 // Chunk boundaries of the LDS-staged SpMV.  With a rank table the chunks are unions of consecutive rank blocks: a rank's rows
-// are the nodes of one subdomain, so a chunk that ends where a subdomain ends stages far fewer columns (7.9 instead of 5.5
-// non-zeros per staged entry at two ranks per chunk) than one that straddles three subdomains; without one, a fixed row count.
+// are the nodes of one subdomain, so a chunk that ends where a subdomain ends stages fewer columns than one that straddles
+// three subdomains (6.3 instead of 5.5 non-zeros per staged entry at one ~85-row rank per chunk).  Small chunks win: two or
+// three ranks per chunk stage even less (7.9) but measured slower (38 and 43 against 34 us: fewer, longer workgroups).
+// Without a rank table, or with ranks too large for a chunk: a fixed row count.
 static std::vector<int32_t> spmv_chunks(nsx_handle *h) {
   const int n = h->gA.host.n_rows;
-  const int target = getenv("NSX_SPMV_R") ? std::max(16, std::min(448, atoi(getenv("NSX_SPMV_R")))) : 192;
+  const int target = getenv("NSX_SPMV_R") ? std::max(16, std::min(448, atoi(getenv("NSX_SPMV_R")))) : 130;
   std::vector<int32_t> bounds{0};
   const std::vector<int32_t> &rk = h->rank_u_h;
   const bool by_rank = !(getenv("NSX_SPMV_BY_RANK") && atoi(getenv("NSX_SPMV_BY_RANK")) == 0) && rk.size() > 2 &&
