@@ -284,7 +284,7 @@ def main():
     ap.add_argument("--schur-blocks", type=int, default=512, help="ILU(0) blocks of the Schur matrix")
     ap.add_argument("--ordering", choices=("colour", "first_touch"), default="colour",
                     help="velocity node order inside a virtual rank (include/nsx_host.h: nsxh_distribute_dofs_ordered)")
-    ap.add_argument("--balance", choices=("cells", "owned"), default="owned",
+    ap.add_argument("--balance", choices=("cells", "owned"), default="cells",
                     help="what the partitioner equalises over the virtual ranks: cells (METIS-like) or owned P2 nodes = ILU block sizes")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-only", action="store_true", help="only the cpu_baseline leg (after a short GPU run that provides its state)")
