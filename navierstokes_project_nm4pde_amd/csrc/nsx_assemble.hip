@@ -354,6 +354,7 @@ void run_assemble(nsx_handle *h, bool first, int flags) {
   HIP_CHECK(hipGetLastError());
   h->assembled = true;
   h->prec_ready = false;
+  if (first) h->schur_valid = false;  // block(1,0) was reassembled
 }
 
 void run_dirichlet(nsx_handle *h, int n_in, const int32_t *dofs_in, const double *vals_in) {

@@ -227,6 +227,9 @@ struct nsx_handle {
   std::vector<int32_t> bc_cache;
   // ---- preconditioner vectors
   nsx::DevBuf<double> diag_D, diag_D_inv, neg_diag_D_inv, lump_M, schur_w;
+  nsx::DevBuf<double> schur_w_prev;        // weights the current Schur product / its factors were computed from
+  bool schur_valid = false;
+  int schur_type = -1;
   // ---- Krylov workspace
   std::vector<nsx::DevBuf<double> *> pool;  // temporary vectors handed out by size
   nsx::DevBuf<double> red_partial;          // reduction partials

@@ -478,6 +478,7 @@ static void refresh_rank_products(nsx_handle *h) {
   h->dbar.alloc(h->rank_u_h.size() - 1);
   h->sched_dirty = true;
   h->prec_ready = false;
+  h->schur_valid = false;  // the Schur ILU blocks follow the tables
 }
 
 void ensure_schedules(nsx_handle *h) {
@@ -746,6 +747,7 @@ void setup_mesh(nsx_handle *h, int n_cells, int n_cells1, const double *cell_coo
   HIP_CHECK(hipStreamSynchronize(h->stream));
   h->have_mesh = true;
   h->assembled = false;
+  h->schur_valid = false;
   h->bc_cache.clear();
 }
 
