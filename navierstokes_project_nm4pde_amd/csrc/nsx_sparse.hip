@@ -258,6 +258,23 @@ static void launch_S(nsx_handle *h, const double *x, double *y, const int32_t *r
 // Distributed products: the rows whose columns are all owned are computed while the ghosts of the input are still on
 // their way (second stream, comm_halo_begin / finish); the rows on the partition interface follow once they have arrived.
 // This is the Epetra_Import + local multiply of every vmult with the import hidden behind the interior rows.
+// y_u = A x_u through the LDS-staged kernel; false if the handle has no chunk table for it
+static bool launch_blocked(nsx_handle *h, const double *vals, const double *x, double *y) {
+  static const bool blocked = !(getenv("NSX_SPMV_BLOCKED") && atoi(getenv("NSX_SPMV_BLOCKED")) == 0);
+  const SpmvBlocked &b = h->blkA;
+  if (!blocked || b.n_chunks == 0 || b.max_rows > 448) return false;
+  const size_t shm = (size_t)b.max_ucols * h->dim * sizeof(double);
+  if (shm > 64 * 1024) return false;
+  const int grid = 8 * cdiv(b.n_chunks, 8);
+  if (h->dim == 2)
+    hipLaunchKernelGGL((k_spmv_blocked<2, 16>), dim3(grid), dim3(256), shm, h->stream, h->N2, b.n_chunks, b.crow.p, h->gA.rowptr.p, b.lidx.p, vals,
+                       b.cptr.p, b.ucols.p, x, y);
+  else
+    hipLaunchKernelGGL((k_spmv_blocked<3, 16>), dim3(grid), dim3(256), shm, h->stream, h->N2, b.n_chunks, b.crow.p, h->gA.rowptr.p, b.lidx.p, vals,
+                       b.cptr.p, b.ucols.p, x, y);
+  return true;
+}
+
 void spmv_F(nsx_handle *h, const double *vals, const double *x, double *y) {
   if (h->dist) {
     double *xx = const_cast<double *>(x);
@@ -269,22 +286,7 @@ void spmv_F(nsx_handle *h, const double *vals, const double *x, double *y) {
     return;
   }
   LaunchScope ls(h, "spmv_F", bytes_vel(h, false));
-  static const bool blocked = !(getenv("NSX_SPMV_BLOCKED") && atoi(getenv("NSX_SPMV_BLOCKED")) == 0);
-  if (blocked && h->blkA.n_chunks > 0 && h->blkA.max_rows <= 448) {
-    const SpmvBlocked &b = h->blkA;
-    const size_t shm = (size_t)b.max_ucols * h->dim * sizeof(double);
-    if (shm <= 64 * 1024) {
-      const int grid = 8 * cdiv(b.n_chunks, 8);
-      if (h->dim == 2)
-        hipLaunchKernelGGL((k_spmv_blocked<2, 16>), dim3(grid), dim3(256), shm, h->stream, h->N2, b.n_chunks, b.crow.p, h->gA.rowptr.p, b.lidx.p, vals,
-                           b.cptr.p, b.ucols.p, x, y);
-      else
-        hipLaunchKernelGGL((k_spmv_blocked<3, 16>), dim3(grid), dim3(256), shm, h->stream, h->N2, b.n_chunks, b.crow.p, h->gA.rowptr.p, b.lidx.p, vals,
-                           b.cptr.p, b.ucols.p, x, y);
-      return;
-    }
-  }
-  launch_vel(h, false, vals, x, nullptr, y, nullptr, h->N2);
+  if (!launch_blocked(h, vals, x, y)) launch_vel(h, false, vals, x, nullptr, y, nullptr, h->N2);
 }
 
 static double bytes_B(nsx_handle *h) { return (4.0 + 8.0 * h->dim) * h->gB.nnz() + 12.0 * h->NP + 8.0 * h->dim * h->N2; }
@@ -324,6 +326,7 @@ void spmv_saddle(nsx_handle *h, const double *x, double *y) {
   {
     LaunchScope ls(h, "spmv_saddle_u", bytes_vel(h, true));
     if (h->dist) launch_vel(h, true, h->vF.p, x, x + h->off_p, y, h->splitVel.interior.p, h->splitVel.n_interior);
+    else if (launch_blocked(h, h->vF.p, x, y)) launch_G(h, x + h->off_p, y, true, nullptr, h->N2);  // F x_u staged through LDS, then += block(0,1) x_p
     else launch_vel(h, true, h->vF.p, x, x + h->off_p, y, nullptr, h->N2);
   }
   {
