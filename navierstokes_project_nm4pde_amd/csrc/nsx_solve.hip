@@ -267,7 +267,8 @@ static bool schur_inputs_unchanged(nsx_handle *h, int type) {
   *flag = 0;
   hipLaunchKernelGGL(k_same_and_keep, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, n, h->schur_w.p, h->schur_w_prev.p, (int *)(h->pub_dev + N_SLOTS + 4));
   HIP_CHECK(hipStreamSynchronize(h->stream));
-  return cache && *flag == 0;
+  // a distributed run rebuilds every time: the ranks would have to agree on the answer first (the rebuild contains collectives)
+  return cache && !h->comm && *flag == 0;
 }
 
 void prec_initialize(nsx_handle *h, int type) {
