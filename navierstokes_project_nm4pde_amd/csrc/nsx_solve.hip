@@ -88,9 +88,9 @@ static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b,
   int accumulated = 0, state = 0, dim = 0;
   bool re_orth = false;
   double *v = vec(0), *p = vec(N_TMP - 1);
-  bool ahead = false;
+  int ahead = 0;  // what of the next iteration is already enqueued: 0 nothing, 1 the operator (A p), 2 operator and preconditioner
   do {
-    ahead = false;
+    ahead = 0;
     if (x_is_zero) {
       v_copy(h, n.n, p, b);  // inner solves only: plain vectors without a ghost gap
       x_is_zero = false;
@@ -116,8 +116,9 @@ static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b,
         A(p, src);
         P(dst, p);
       };
-      if (!ahead) apply_AP(vv, vec(inner));
-      ahead = false;
+      if (ahead == 0) apply_AP(vv, vec(inner));
+      else if (ahead == 1) P(vv, p);
+      ahead = 0;
       dim = inner + 1;
       // modified Gram-Schmidt, h(i) = vv . v_i after removing the previous components (add_and_dot chain)
       const bool consider = !re_orth && (inner % 5 == 4);
@@ -129,14 +130,19 @@ static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b,
       // once per solve (the iteration that converges); p is a temporary.
       const std::function<void()> next_A = [&]() {
         if (inner + 1 < N_TMP - 2) {
-          apply_AP(vec(inner + 2), vv);  // operator AND preconditioner of the next iteration: both depend on vv alone
-          ahead = true;
+          if (AP) {  // inner solves on F: operator AND preconditioner of the next iteration are plain kernels that depend on vv alone
+            apply_AP(vec(inner + 2), vv);
+            ahead = 2;
+          } else {   // the outer solve's preconditioner runs Krylov solves of its own (host round trips, the same scalar slots): only A
+            A(p, vv);
+            ahead = 1;
+          }
         }
       };
       bool normalized = v_mgs(h, n, vv, dim, basis, S_H, !re_orth, hh, &next_A, consider);
       if (h->mgs_redo_ahead) {  // the sweep fell back to the launch-per-link chain: A * vv was enqueued on an unfinished vv
         h->mgs_redo_ahead = false;
-        ahead = false;
+        ahead = 0;
       }
       double s = std::sqrt(hh[dim]);
       if (consider) {
