@@ -109,7 +109,6 @@ struct IluSchedule {
   int blocks_per_wave = 1, n_waves = 0, max_wave_rows = 0;
   bool packed_ok = false;
   DevBuf<int32_t> pk_wave_blk;  // [n_waves*blocks_per_wave] blocks served by each wave (-1 = none)
-  DevBuf<int32_t> pk_wave_blk_pad;  // the same for blocks_per_wave == 1, padded with -1 to a multiple of 8 waves (fused kernel's grid)
   DevBuf<int32_t> pk_slab_ptr;  // [2*n_waves+1]: forward slabs, then backward slabs, per wave
   DevBuf<int32_t> pk_meta;      // [n_slabs*64]
   DevBuf<int32_t> pk_slot_of;   // [nnz]: slot of every in-block off-diagonal CSR entry, -1 otherwise
@@ -311,7 +310,6 @@ void spmv_saddle(nsx_handle *h, const double *x, double *y);                    
 void spmv_G(nsx_handle *h, const double *xp, double *yu, bool accumulate);                  // y_u (+)= block(0,1) x_p
 void spmv_B(nsx_handle *h, const double *xu, double *yp);                                   // y_p = block(1,0) x_u
 void spmv_S(nsx_handle *h, const double *x, double *y);                                     // y = negative_S x
-bool spmv_ilu_F(nsx_handle *h, const double *x, double *z);                                 // z = ILU(F)^-1 (F x) in one launch, if the layout allows
 void schur_numeric(nsx_handle *h, const double *w);                                         // S = B diag(w) G
 void ilu_factor(nsx_handle *h, const DevCsr &g, IluSchedule &s, const double *vals, double *lu, const char *name);
 void ilu_check(nsx_handle *h);  // after a synchronisation: throws if a factorisation kernel reported a failure

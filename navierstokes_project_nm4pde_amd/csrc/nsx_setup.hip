@@ -347,11 +347,7 @@ void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> 
             (double)used / (double)std::max<int64_t>(1, s.n_slabs * 64));
   }
   s.pk_wave_blk.upload(wave_blk, h->stream);
-  {
-    std::vector<int32_t> pad(wave_blk);
-    if (BPW == 1) pad.resize((size_t)8 * ((nw + 7) / 8), -1);
-    s.pk_wave_blk_pad.upload(pad, h->stream);
-  }
+
   s.pk_slab_ptr.upload(slab_ptr, h->stream);
   s.pk_meta.upload(meta, h->stream);
   s.pk_slot_of.upload(slot_of, h->stream);

@@ -70,10 +70,12 @@ enum { S_H = 8 /* 8..8+N_TMP */, S_NRM = 40, S_H2 = 41 /* re-orthogonalisation c
 // operators (SpMV, ILU) overwrite every owned entry, so their temporaries are handed out as they come from the pool.
 // x_is_zero: the caller has just zeroed x (Prec.hpp:401): the residual b - A x of the first cycle is b without touching the matrix
 // (deal.II forms it through vmult + sadd; -1 * (A 0) + b gives the same numbers).
-// AP (optional): dst = P (A src) in one launch where the layout allows it (returns false otherwise); used inside the Arnoldi loop.
-using OpFused = std::function<bool(double *dst, const double *src)>;
+// plain_P: the preconditioner is a plain kernel (ILU), not a solver with host round trips of its own: the operator AND the
+// preconditioner of the next iteration are then enqueued behind the Gram-Schmidt sweep, before its coefficients are waited for.
+// (Fusing the two into one launch per rank block — four waves for the block's rows of A x, then one wave for the sweeps — was
+// tried: 100 us against 35 + 35, the workgroups of the product hold LDS and registers the sweeping waves of other blocks need.)
 static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b, const Op &P, Span n, int len, double tol, int maxiter,
-                         bool zero_new = false, bool x_is_zero = false, const OpFused *AP = nullptr) {
+                         bool zero_new = false, bool x_is_zero = false, bool plain_P = false) {
   SolveResult res{1, 0, 0.0};
   std::vector<std::unique_ptr<Tmp>> tmp(N_TMP);
   auto vec = [&](int i) -> double * {
@@ -112,7 +114,6 @@ static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b,
       double *vv = vec(inner + 1);
       // (already enqueued behind the previous iteration's Gram-Schmidt sweep when `ahead`)
       auto apply_AP = [&](double *dst, const double *src) {  // dst = P (A src)
-        if (AP && (*AP)(dst, src)) return;
         A(p, src);
         P(dst, p);
       };
@@ -130,7 +131,7 @@ static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b,
       // once per solve (the iteration that converges); p is a temporary.
       const std::function<void()> next_A = [&]() {
         if (inner + 1 < N_TMP - 2) {
-          if (AP) {  // inner solves on F: operator AND preconditioner of the next iteration are plain kernels that depend on vv alone
+          if (plain_P) {  // inner solves on F: operator AND preconditioner of the next iteration are plain kernels that depend on vv alone
             apply_AP(vec(inner + 2), vv);
             ahead = 2;
           } else {   // the outer solve's preconditioner runs Krylov solves of its own (host round trips, the same scalar slots): only A
@@ -345,7 +346,6 @@ void prec_vmult(nsx_handle *h, int type, double tol, int maxit, double *dst, con
   Op Fm = [h](double *d, const double *s) { spmv_F(h, h->vF.p, s, d); };
   Op Sm = [h](double *d, const double *s) { spmv_S(h, s, d); };
   Op PF = [h, dim](double *d, const double *s) { ilu_solve(h, h->gA, h->schedF, h->luF.p, s, d, dim, "ilu_solve_F"); };
-  OpFused FPF = [h](double *d, const double *s) { return spmv_ilu_F(h, s, d); };  // preconditioner_F.vmult(F->vmult(.)) of the Arnoldi loop
   Op PS = [h](double *d, const double *s) { ilu_solve(h, h->gS, h->schedS, h->luS.p, s, d, 1, "ilu_solve_S"); };
   OpDot PSdot = [h](double *d, const double *s, int slot) { return ilu_solve(h, h->gS, h->schedS, h->luS.p, s, d, 1, "ilu_solve_S", slot); };
   // SolverCG on negative_S_tilde with tolerance tol * |b| (Prec.hpp:179-182,388-390,500-502): one persistent launch where the
@@ -361,7 +361,7 @@ void prec_vmult(nsx_handle *h, int type, double tol, int maxit, double *dst, con
     Tmp yu(h, len_u), yp(h, len_p), tmp(h, len_p), tmp2(h, len_u), res(h, len_u);
     v_copy(h, n_u, yu.p(), src_u);                                                            // :375
     v_copy(h, n_p, yp.p(), src_p);                                                            // :376
-    count(st, true, gmres(h, Fm, yu.p(), src_u, PF, n_u, len_u, tol * norm2(h, n_u, src_u), maxit, false, false, &FPF)); // :371-382
+    count(st, true, gmres(h, Fm, yu.p(), src_u, PF, n_u, len_u, tol * norm2(h, n_u, src_u), maxit, false, false, true)); // :371-382
     spmv_B(h, yu.p(), tmp.p());                                                               // :385
     v_add(h, n_p, tmp.p(), -1.0, src_p);                                                      // :386
     count(st, false, cg_S(yp.p(), tmp.p()));                                                  // :388-390
@@ -369,13 +369,13 @@ void prec_vmult(nsx_handle *h, int type, double tol, int maxit, double *dst, con
     spmv_G(h, dst_p, tmp2.p(), false);                                                        // :398
     v_zero(h, n_u, res.p());                                                                  // :401
     v_copy(h, n_u, dst_u, yu.p());                                                            // :402
-    count(st, true, gmres(h, Fm, res.p(), tmp2.p(), PF, n_u, len_u, tol * norm2(h, n_u, tmp2.p()), maxit, false, true, &FPF));  // :403-405
+    count(st, true, gmres(h, Fm, res.p(), tmp2.p(), PF, n_u, len_u, tol * norm2(h, n_u, tmp2.p()), maxit, false, true, true));  // :403-405
     v_sadd(h, n_u, dst_u, -1., 1., res.p());  // dst.block(0).sadd(-1,res): dst = -dst + res            :406
   } else if (type == NSX_PREC_SIMPLE) {  // Prec.hpp:151-205
     Tmp sol1_u(h, len_u), sol1_p(h, len_p), temp_1(h, len_p), tmp(h, len_u);
     v_copy(h, n_u, sol1_u.p(), src_u);                                                             // :168
     v_copy(h, n_p, sol1_p.p(), src_p);                                                             // :169
-    count(st, true, gmres(h, Fm, sol1_u.p(), src_u, PF, n_u, len_u, tol * norm2(h, n_u, src_u), maxit, false, false, &FPF));  // :157-173
+    count(st, true, gmres(h, Fm, sol1_u.p(), src_u, PF, n_u, len_u, tol * norm2(h, n_u, src_u), maxit, false, false, true));  // :157-173
     spmv_B(h, sol1_u.p(), temp_1.p());                                                             // :175
     v_add(h, n_p, temp_1.p(), -1.0, src_p);                                                        // :176
     count(st, false, cg_S(sol1_p.p(), temp_1.p()));                                               // :179-182
@@ -387,7 +387,7 @@ void prec_vmult(nsx_handle *h, int type, double tol, int maxit, double *dst, con
     v_add(h, n_u, dst_u, -1.0, tmp.p());                                                           // :203
   } else if (type == NSX_PREC_ASIMPLE) {  // Prec.hpp:254-311 (dst is the caller's vector: its content is the initial guess)
     Tmp tmp_u(h, len_u), tmp_p(h, len_p);
-    count(st, true, gmres(h, Fm, dst_u, src_u, PF, n_u, len_u, tol * norm2(h, n_u, src_u), maxit, false, false, &FPF));  // :271-273
+    count(st, true, gmres(h, Fm, dst_u, src_u, PF, n_u, len_u, tol * norm2(h, n_u, src_u), maxit, false, false, true));  // :271-273
     spmv_B(h, dst_u, dst_p);                                                                   // :280
     v_sadd(h, n_p, dst_p, -1.0, 1.0, src_p);                                                   // :281
     v_copy(h, n_p, tmp_p.p(), dst_p);                                                          // :282

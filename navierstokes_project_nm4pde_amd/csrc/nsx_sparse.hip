@@ -1059,114 +1059,6 @@ __global__ __launch_bounds__(64) void k_ilu_solve_packed(int bpw, const int32_t 
   }
 }
 
-// ---- operator application and triangular solve of one rank block in one launch ---------------------------------------------
-// z = ILU^-1 (A x) for the inner GMRES on F (Prec.hpp:173,273,382,405: F->vmult followed by preconditioner_F.vmult).  One
-// workgroup per rank block: its four waves compute the block's rows of A x (16 lanes per row, the loads of two rows in
-// flight, x gathered through L2) straight into the LDS vector the triangular sweeps work on; then waves 1-3 leave and wave 0
-// runs the packed sweeps of k_ilu_solve_packed.  The product never goes to HBM and back (16 MB per application), one launch
-// boundary disappears, and the bandwidth-bound rows of some blocks overlap the latency-bound sweeps of others.
-// Same arithmetic per entry as the two kernels it replaces; the row sums use the order of k_spmv_vel (not of the LDS-staged
-// kernel), which is a rounding-level difference.
-template <int NCOMP, int LW, int PF>
-__global__ __launch_bounds__(256) void k_spmv_ilu_packed(const int32_t *__restrict__ wave_blk, const int32_t *__restrict__ bptr,
-                                                         const int32_t *__restrict__ slab_ptr, const int32_t *__restrict__ meta,
-                                                         const double *__restrict__ val, const double *__restrict__ dinv,
-                                                         const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
-                                                         const double *__restrict__ av, const double *__restrict__ x, double *__restrict__ z) {
-  extern __shared__ double xs[];  // [rows of the block][NCOMP]
-  __shared__ int rps[ILU_DENSE_ROWS + 1];
-  // XCD-aware: neighbouring blocks (which share the x entries they gather) on the same XCD's L2; grid is a multiple of 8
-  const int per_xcd = gridDim.x >> 3;
-  const int w = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  const int blk = wave_blk[w];
-  if (blk < 0) return;
-  const int r0 = bptr[blk], nloc = bptr[blk + 1] - r0;
-  for (int t = threadIdx.x; t <= nloc; t += 256) rps[t] = rp[r0 + t];
-  __syncthreads();
-  {
-    constexpr int W = 16, G = 256 / W, U = 4;
-    const int grp = threadIdx.x / W, lane = threadIdx.x % W;
-    double a[U], na[U];
-    int c[U], nc[U];
-    auto fetch = [&](int q, double(&va)[U], int(&vc)[U]) {
-      const bool live = q < nloc;
-      const int p0 = live ? rps[q] + lane : 0, e = live ? rps[q + 1] : 0;
-#pragma unroll
-      for (int k = 0; k < U; ++k) {
-        const int p = p0 + k * W;
-        const bool ok = p < e;
-        va[k] = ok ? av[p] : 0.0;
-        vc[k] = ok ? ci[p] : 0;
-      }
-    };
-    auto consume = [&](int q, const double(&va)[U], const int(&vc)[U]) {
-      if (q >= nloc) return;
-      double acc[NCOMP];
-#pragma unroll
-      for (int cc = 0; cc < NCOMP; ++cc) acc[cc] = 0.0;
-#pragma unroll
-      for (int k = 0; k < U; ++k) {
-        const double *xj = x + (size_t)vc[k] * NCOMP;
-#pragma unroll
-        for (int cc = 0; cc < NCOMP; ++cc) acc[cc] += va[k] * xj[cc];
-      }
-      const int e = rps[q + 1];
-      for (int p = rps[q] + lane + U * W; p < e; p += W) {  // rows longer than U * W entries (rare)
-        const double av_ = av[p];
-        const double *xj = x + (size_t)ci[p] * NCOMP;
-#pragma unroll
-        for (int cc = 0; cc < NCOMP; ++cc) acc[cc] += av_ * xj[cc];
-      }
-#pragma unroll
-      for (int cc = 0; cc < NCOMP; ++cc) acc[cc] = group_sum<W>(acc[cc]);
-      if (lane == 0) {
-#pragma unroll
-        for (int cc = 0; cc < NCOMP; ++cc) xs[q * NCOMP + cc] = acc[cc];
-      }
-    };
-    int q = grp;
-    fetch(q, a, c);
-    fetch(q + G, na, nc);
-    for (; q < nloc; q += 2 * G) {
-      consume(q, a, c);
-      fetch(q + 2 * G, a, c);
-      consume(q + G, na, nc);
-      fetch(q + 3 * G, na, nc);
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x >= 64) return;  // the sweeps are one wave's work
-  const int lane = threadIdx.x;
-  const int s0 = slab_ptr[2 * w], s1 = slab_ptr[2 * w + 1], s2 = slab_ptr[2 * w + 2];
-  packed_sweep<NCOMP, LW, PF>(s0, s1, meta, val, xs, lane);  // y = L^{-1} b
-  for (int t = lane; t < nloc; t += 64) {                    // y *= D^{-1}
-    const double d = dinv[r0 + t];
-#pragma unroll
-    for (int cc = 0; cc < NCOMP; ++cc) xs[t * NCOMP + cc] *= d;
-  }
-  packed_sweep<NCOMP, LW, PF>(s1, s2, meta, val, xs, lane);  // x = U^{-1} y
-  for (int t = lane; t < nloc * NCOMP; t += 64) z[(size_t)r0 * NCOMP + t] = xs[t];
-}
-
-// z = ILU(F)^-1 (F x) in one launch; false: the layout does not allow it (the caller then runs the two kernels)
-bool spmv_ilu_F(nsx_handle *h, const double *x, double *z) {
-  static const bool fused = !(getenv("NSX_FUSE_F") && atoi(getenv("NSX_FUSE_F")) == 0);
-  const IluSchedule &s = h->schedF;
-  if (!fused || h->dist || !s.packed_ok || s.blocks_per_wave != 1 || s.lanes_per_row != 8 || s.max_rows > ILU_DENSE_ROWS) return false;
-  const size_t shm = (size_t)s.max_wave_rows * h->dim * sizeof(double);
-  if (shm > 48 * 1024) return false;
-  const DevCsr &g = h->gA;
-  LaunchScope ls(h, "spmv_ilu_F", bytes_vel(h, false) + 12.0 * g.nnz() + (double)g.n_rows() * (4 + 8.0 * h->dim));
-  const int grid = 8 * cdiv(s.n_waves, 8);
-  if (h->dim == 2)
-    hipLaunchKernelGGL((k_spmv_ilu_packed<2, 8, 8>), dim3(grid), dim3(256), shm, h->stream, s.pk_wave_blk_pad.p, s.block_ptr.p, s.pk_slab_ptr.p, s.pk_meta.p,
-                       s.pk_val.p, s.pk_dinv.p, g.rowptr.p, g.colind.p, h->vF.p, x, z);
-  else
-    hipLaunchKernelGGL((k_spmv_ilu_packed<3, 8, 8>), dim3(grid), dim3(256), shm, h->stream, s.pk_wave_blk_pad.p, s.block_ptr.p, s.pk_slab_ptr.p, s.pk_meta.p,
-                       s.pk_val.p, s.pk_dinv.p, g.rowptr.p, g.colind.p, h->vF.p, x, z);
-  return true;
-}
-
 template <int NCOMP, int LW>
 static void launch_packed(nsx_handle *h, const IluSchedule &s, const double *b, double *x, double *dot_partial) {
   const size_t shm = (size_t)s.max_wave_rows * NCOMP * sizeof(double);
