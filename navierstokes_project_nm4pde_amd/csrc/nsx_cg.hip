@@ -124,13 +124,6 @@ __device__ __forceinline__ bool cg_collect(double (&tot)[NV], unsigned long long
   for (int v = 0; v < NV; ++v) tot[v] = bc[v];
   return *s_err == 0;
 }
-template <int NV>
-__device__ __forceinline__ bool cg_exchange(const double (&part)[NV], double (&tot)[NV], unsigned long long *box, int e, int nwg, double (*sh)[CG_NV * 8],
-                                            double *bc, int *s_err) {
-  cg_post<NV>(part, box, e, nwg, sh, s_err);
-  return cg_collect<NV>(tot, box, e, bc, s_err);
-}
-
 // ---- packed operator stream ------------------------------------------------------------------------------------------
 // A latency-bound kernel must not chase pointers: rowptr -> colind -> x is three dependent trips through memory per row.
 // At setup (build_cg_plan) the rows of every Schur block are laid out as slabs of 256 slots — slab (round r, chunk c) holds
@@ -188,7 +181,7 @@ __device__ __forceinline__ void cg_block_spmv(int s0, int s1, const double *__re
 }
 #undef NSX_CG_LOAD
 
-__global__ __launch_bounds__(CG_THREADS) void k_cg_schur(int n_blocks, const int32_t *__restrict__ bptr, const int32_t *__restrict__ u_ptr,
+__global__ __launch_bounds__(CG_THREADS) void k_cg_schur(const int32_t *__restrict__ bptr, const int32_t *__restrict__ u_ptr,
                                                   const int32_t *__restrict__ u_cols, const int32_t *__restrict__ s_ptr,
                                                   const double *__restrict__ sval, const uint16_t *__restrict__ slidx,
                                                   const int32_t *__restrict__ sinfo, const int64_t *__restrict__ dn_off,
@@ -483,7 +476,7 @@ bool cg_schur_persistent(nsx_handle *h, double *x, const double *b, double rtol,
   {
     LaunchScope ls(h, "cg_S", 0.0);
     pe = ls.e;
-    hipLaunchKernelGGL(k_cg_schur, dim3(s.n_blocks), dim3(CG_THREADS), 0, h->stream, s.n_blocks, s.block_ptr.p, pl.u_ptr.p, pl.u_cols.p, pl.s_ptr.p, pl.s_val.p,
+    hipLaunchKernelGGL(k_cg_schur, dim3(s.n_blocks), dim3(CG_THREADS), 0, h->stream, s.block_ptr.p, pl.u_ptr.p, pl.u_cols.p, pl.s_ptr.p, pl.s_val.p,
                        pl.s_lidx.p, pl.s_info.p, s.dn_off.p, s.dn_P.p, b, x, D0, D1, H, rtol, maxiter, box, box_other, pub_vals, pub_flag, seq,
                        err_dev);
   }
