@@ -354,14 +354,12 @@ void run_assemble(nsx_handle *h, bool first, int flags) {
   HIP_CHECK(hipGetLastError());
   h->assembled = true;
   h->prec_ready = false;
-  h->slabF.values_current = false;    // system(0,0) changed
   if (first) h->schur_valid = false;  // block(1,0) was reassembled
 }
 
 void run_dirichlet(nsx_handle *h, int n_in, const int32_t *dofs_in, const double *vals_in) {
   if (!h->assembled) NSX_THROW(NSX_ERR_ARG, "assemble before applying boundary values");
   HIP_CHECK(hipSetDevice(h->prm.device));
-  h->slabF.values_current = false;  // constrained rows of system(0,0) are rewritten
   const int dim = h->dim;
   if (n_in < 0 || (n_in > 0 && (!dofs_in || !vals_in))) NSX_THROW(NSX_ERR_ARG, "bad boundary value arrays");
   // the map uses global dofs; a rank applies the entries it owns (MatrixTools::apply_boundary_values does the same per rank)

@@ -170,18 +170,6 @@ struct CgPlan {
   DevBuf<double> s_val;
 };
 
-// Slab layout of the scalar velocity operator for the inner GMRES on F (k_spmv_slab): per chunk (= rank block) the rows in
-// rounds of 16, each round in slabs of 256 slots (entry 16c + lane of row 16r + grp for thread (grp, lane)); 8-B value + 16-bit
-// index into the chunk's unique-column list.  Every load address depends on the loop counter alone.
-struct SlabPlan {
-  bool ok = false, values_current = false;
-  int n_chunks = 0, max_ucols = 0;
-  int64_t n_slots = 0;
-  DevBuf<int32_t> crow, u_ptr, u_cols, s_ptr, s_info, s_src;
-  DevBuf<uint16_t> s_lidx;
-  DevBuf<double> s_val;
-};
-
 struct ProfEntry {
   int64_t launches = 0;
   double bytes = 0;  // algorithmic bytes summed over the launches (a scope's size may vary: Gram-Schmidt sweeps)
@@ -222,7 +210,6 @@ struct nsx_handle {
   // ---- graphs and values
   nsx::DevCsr gA, gG, gB, gS, gPM;
   nsx::SpmvBlocked blkA;
-  nsx::SlabPlan slabF;                     // system(0,0) as slabs: refreshed when a preconditioner is initialised (F is final then)
   nsx::DevBuf<double> vS0, vMass, vStiff, vConv, vF, vG, vB, vPM, vSchur, luF, luS;
   nsx::DevBuf<int32_t> bt_of_g;            // for every G entry (i,k): position of (k,i) in the B graph
   nsx::GatherMap gmA, gmG, gmB, gmPM;
@@ -393,8 +380,6 @@ unsigned long long publish_scalars(nsx_handle *h, int slot0, int count);  // asy
 void collect_published(nsx_handle *h, unsigned long long seq, int slot0, int count, double *out);
 void wait_published(nsx_handle *h, unsigned long long seq);  // host waits for the sequence number of a publication
 // persistent CG on the Schur complement (nsx_cg.hip); false: not applicable here, use the launch-per-operation solver
-void build_slab_plan(nsx_handle *h, const std::vector<int32_t> &bounds);  // with the ILU schedules (chunks = rank blocks)
-void slab_pack_F(nsx_handle *h);     // after the last change of system(0,0) in a step
 void build_cg_plan(nsx_handle *h);   // with the ILU schedules
 void cg_pack_values(nsx_handle *h);  // after every schur_numeric
 bool cg_schur_persistent(nsx_handle *h, double *x, const double *b, double rtol, int maxiter, int *steps, double *last, int *status);

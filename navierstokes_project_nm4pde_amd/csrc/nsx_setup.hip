@@ -497,11 +497,7 @@ static void refresh_rank_products(nsx_handle *h) {
 
 void ensure_schedules(nsx_handle *h) {
   if (!h->sched_dirty) return;
-  if (!h->dist) {
-    const std::vector<int32_t> chunks = spmv_chunks(h);
-    build_blocked(h, h->gA.host, chunks, h->blkA);
-    build_slab_plan(h, chunks);
-  }
+  if (!h->dist) build_blocked(h, h->gA.host, spmv_chunks(h), h->blkA);
   const int lwF = getenv("NSX_LW_F") ? atoi(getenv("NSX_LW_F")) : 8, lwS = getenv("NSX_LW_S") ? atoi(getenv("NSX_LW_S")) : 32;
   const int bpwF = getenv("NSX_BPW_F") ? atoi(getenv("NSX_BPW_F")) : 1, bpwS = getenv("NSX_BPW_S") ? atoi(getenv("NSX_BPW_S")) : 1;
   const bool wideF = !(getenv("NSX_WIDE") && atoi(getenv("NSX_WIDE")) == 0);

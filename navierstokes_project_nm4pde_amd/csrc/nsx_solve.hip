@@ -313,7 +313,6 @@ void prec_initialize(nsx_handle *h, int type) {
   v_scale(h, n_u, h->schur_w.p, -1.0);
   // preconditioner_F.initialize(*F)   (Prec.hpp:147,250,361,470): F changes every step
   ilu_factor(h, h->gA, h->schedF, h->vF.p, h->luF.p, "ilu_factor_F");
-  slab_pack_F(h);  // F is final for this step: its slab copy for the inner solves' products
   // negative_S and preconditioner_S.initialize(negative_S)   (Prec.hpp:144-148,248-251,358-362,468-471).  The reference
   // rebuilds both in every step.  Their only inputs are block(1,0) (assembled once) and the weights w; when w is bit for bit
   // the vector of the previous initialisation (Yosida: D = diag(M / deltat) and the Dirichlet mask do not change in time) the

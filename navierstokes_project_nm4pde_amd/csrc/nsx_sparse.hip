@@ -212,156 +212,6 @@ __global__ __launch_bounds__(256) void k_spmv_blocked(int n_rows, int n_chunks, 
   }
 }
 
-// ---- slab SpMV ---------------------------------------------------------------------------------------------------------
-// y[i][c] = sum_j A[i,j] x[j][c] from the slab layout (SlabPlan): the value / index loads of a chunk have addresses that depend
-// on the loop counter alone, so two register sets of SLAB_PF slabs are in flight from the first instruction on and overlap the
-// staging of the chunk's x entries in LDS; no row pointers, no per-row dependent load rounds.
-constexpr int SLAB_PF = 8;
-template <int DIM>
-__global__ __launch_bounds__(256) void k_spmv_slab(int n_chunks, const int32_t *__restrict__ crow, const int32_t *__restrict__ u_ptr,
-                                                   const int32_t *__restrict__ u_cols, const int32_t *__restrict__ s_ptr,
-                                                   const double *__restrict__ sval, const uint16_t *__restrict__ slidx,
-                                                   const int32_t *__restrict__ sinfo, const double *__restrict__ x, double *__restrict__ y) {
-  extern __shared__ double xst[];
-  const int per_xcd = gridDim.x >> 3;  // XCD-aware chunk mapping, as k_spmv_blocked
-  const int chunk = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if (chunk >= n_chunks) return;
-  const int tid = threadIdx.x, grp = tid >> 4, lane = tid & 15;
-  const int r0 = crow[chunk], r1 = crow[chunk + 1];
-  const int u0 = u_ptr[chunk], nu = u_ptr[chunk + 1] - u0;
-  const int s0 = s_ptr[chunk], s1 = s_ptr[chunk + 1];
-  double va[SLAB_PF], vb[SLAB_PF];
-  int la[SLAB_PF], lb[SLAB_PF];
-#define NSX_SL_LOAD(V, L, S0)                                   \
-  _Pragma("unroll") for (int k = 0; k < SLAB_PF; ++k) {         \
-    const int s_ = (S0) + k;                                    \
-    const bool ok_ = s_ < s1;                                   \
-    V[k] = ok_ ? sval[(size_t)s_ * 256 + tid] : 0.0;            \
-    L[k] = ok_ ? (int)slidx[(size_t)s_ * 256 + tid] : 0;        \
-  }
-  NSX_SL_LOAD(va, la, s0)  // on their way while x is staged
-  for (int t = tid; t < nu; t += 256) {
-    const double *xj = x + (size_t)u_cols[u0 + t] * DIM;
-#pragma unroll
-    for (int c = 0; c < DIM; ++c) xst[t * DIM + c] = xj[c];
-  }
-  __syncthreads();
-  double acc[DIM];
-#pragma unroll
-  for (int c = 0; c < DIM; ++c) acc[c] = 0.0;
-#define NSX_SL_USE(V, L, S0)                                    \
-  _Pragma("unroll") for (int k = 0; k < SLAB_PF; ++k) {         \
-    const int s_ = (S0) + k;                                    \
-    if (s_ < s1) {                                              \
-      const double *xj = xst + L[k] * DIM;                      \
-      _Pragma("unroll") for (int c = 0; c < DIM; ++c) acc[c] += V[k] * xj[c]; \
-      const int inf = sinfo[s_];                                \
-      if (inf & 0x8000) {                                       \
-        const int row = r0 + (inf & 0x7fff) * 16 + grp;         \
-        _Pragma("unroll") for (int c = 0; c < DIM; ++c) acc[c] = group_sum<16>(acc[c]); \
-        if (lane == 0 && row < r1) {                            \
-          _Pragma("unroll") for (int c = 0; c < DIM; ++c) y[(size_t)row * DIM + c] = acc[c]; \
-        }                                                       \
-        _Pragma("unroll") for (int c = 0; c < DIM; ++c) acc[c] = 0.0; \
-      }                                                         \
-    }                                                           \
-  }
-  for (int sb = s0; sb < s1; sb += 2 * SLAB_PF) {
-    NSX_SL_LOAD(vb, lb, sb + SLAB_PF)
-    NSX_SL_USE(va, la, sb)
-    NSX_SL_LOAD(va, la, sb + 2 * SLAB_PF)
-    NSX_SL_USE(vb, lb, sb + SLAB_PF)
-  }
-#undef NSX_SL_LOAD
-#undef NSX_SL_USE
-}
-
-__global__ void k_slab_pack(int64_t n_slots, const int32_t *__restrict__ src, const double *__restrict__ v, double *__restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_slots) out[i] = src[i] >= 0 ? v[src[i]] : 0.0;
-}
-
-void build_slab_plan(nsx_handle *h, const std::vector<int32_t> &bounds) {
-  SlabPlan &pl = h->slabF;
-  pl.ok = pl.values_current = false;
-  static const bool enabled = !(getenv("NSX_SPMV_SLAB") && atoi(getenv("NSX_SPMV_SLAB")) == 0);
-  if (!enabled || h->dist) return;
-  const Csr &g = h->gA.host;
-  const int nc = (int)bounds.size() - 1;
-  std::vector<int32_t> u_ptr(nc + 1, 0), u_cols, s_ptr(nc + 1, 0), s_info, s_src, tmp;
-  std::vector<uint16_t> s_lidx;
-  int max_ucols = 0;
-  for (int c = 0; c < nc; ++c) {
-    const int r0 = bounds[c], r1 = bounds[c + 1], n = r1 - r0;
-    if (n > 16 * 0x7fff) return;
-    tmp.assign(g.colind.begin() + g.rowptr[r0], g.colind.begin() + g.rowptr[r1]);
-    std::sort(tmp.begin(), tmp.end());
-    tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-    if (tmp.size() > 65535) return;
-    max_ucols = std::max(max_ucols, (int)tmp.size());
-    u_cols.insert(u_cols.end(), tmp.begin(), tmp.end());
-    u_ptr[c + 1] = (int32_t)u_cols.size();
-    for (int r = 0; r * 16 < n; ++r) {
-      int maxlen = 0;
-      for (int q = 16 * r; q < std::min(n, 16 * r + 16); ++q) maxlen = std::max(maxlen, g.rowptr[r0 + q + 1] - g.rowptr[r0 + q]);
-      const int chunks = std::max(1, (maxlen + 15) / 16);
-      for (int k = 0; k < chunks; ++k) {
-        s_info.push_back(r | (k == chunks - 1 ? 0x8000 : 0));
-        for (int t = 0; t < 256; ++t) {
-          const int q = 16 * r + (t >> 4), e = 16 * k + (t & 15);
-          int32_t src = -1;
-          uint16_t li = 0;
-          if (q < n && g.rowptr[r0 + q] + e < g.rowptr[r0 + q + 1]) {
-            src = g.rowptr[r0 + q] + e;
-            li = (uint16_t)(std::lower_bound(tmp.begin(), tmp.end(), g.colind[src]) - tmp.begin());
-          }
-          s_src.push_back(src);
-          s_lidx.push_back(li);
-        }
-      }
-    }
-    s_ptr[c + 1] = (int32_t)s_info.size();
-  }
-  if ((size_t)max_ucols * h->dim * sizeof(double) > 64 * 1024) return;
-  pl.n_chunks = nc;
-  pl.max_ucols = max_ucols;
-  pl.n_slots = (int64_t)s_src.size();
-  pl.crow.upload(bounds, h->stream);
-  pl.u_ptr.upload(u_ptr, h->stream);
-  pl.u_cols.upload(u_cols, h->stream);
-  pl.s_ptr.upload(s_ptr, h->stream);
-  pl.s_info.upload(s_info, h->stream);
-  pl.s_src.upload(s_src, h->stream);
-  pl.s_lidx.upload(s_lidx, h->stream);
-  pl.s_val.alloc((size_t)pl.n_slots);
-  pl.ok = true;
-  if (getenv("NSX_DEBUG"))
-    fprintf(stderr, "[nsx] slab spmv: %d chunks, %lld slabs (fill %.2f), unique cols/chunk max %d\n", nc, (long long)s_info.size(),
-            (double)g.nnz() / (double)std::max<int64_t>(1, pl.n_slots), max_ucols);
-}
-
-void slab_pack_F(nsx_handle *h) {
-  SlabPlan &pl = h->slabF;
-  if (!pl.ok) return;
-  LaunchScope ls(h, "slab_pack_F", 20.0 * (double)pl.n_slots);
-  hipLaunchKernelGGL(k_slab_pack, dim3(cdiv(pl.n_slots, 256)), dim3(256), 0, h->stream, pl.n_slots, pl.s_src.p, h->vF.p, pl.s_val.p);
-  pl.values_current = true;
-}
-
-static bool launch_slab(nsx_handle *h, const double *vals, const double *x, double *y) {
-  const SlabPlan &pl = h->slabF;
-  if (!pl.ok || !pl.values_current || vals != h->vF.p) return false;
-  const size_t shm = (size_t)pl.max_ucols * h->dim * sizeof(double);
-  const int grid = 8 * cdiv(pl.n_chunks, 8);
-  if (h->dim == 2)
-    hipLaunchKernelGGL((k_spmv_slab<2>), dim3(grid), dim3(256), shm, h->stream, pl.n_chunks, pl.crow.p, pl.u_ptr.p, pl.u_cols.p, pl.s_ptr.p, pl.s_val.p,
-                       pl.s_lidx.p, pl.s_info.p, x, y);
-  else
-    hipLaunchKernelGGL((k_spmv_slab<3>), dim3(grid), dim3(256), shm, h->stream, pl.n_chunks, pl.crow.p, pl.u_ptr.p, pl.u_cols.p, pl.s_ptr.p, pl.s_val.p,
-                       pl.s_lidx.p, pl.s_info.p, x, y);
-  return true;
-}
-
 static double bytes_vel(nsx_handle *h, bool with_g) {
   double b = 12.0 * h->gA.nnz() + (double)h->N2 * (4 + 8.0 * h->dim * 2);
   if (with_g) b += (4.0 + 8.0 * h->dim) * h->gG.nnz() + 4.0 * h->N2 + 8.0 * h->NP;
@@ -410,7 +260,6 @@ static void launch_S(nsx_handle *h, const double *x, double *y, const int32_t *r
 // This is the Epetra_Import + local multiply of every vmult with the import hidden behind the interior rows.
 // y_u = A x_u through the LDS-staged kernel; false if the handle has no chunk table for it
 static bool launch_blocked(nsx_handle *h, const double *vals, const double *x, double *y) {
-  if (launch_slab(h, vals, x, y)) return true;
   static const bool blocked = !(getenv("NSX_SPMV_BLOCKED") && atoi(getenv("NSX_SPMV_BLOCKED")) == 0);
   const SpmvBlocked &b = h->blkA;
   if (!blocked || b.n_chunks == 0 || b.max_rows > 448) return false;
