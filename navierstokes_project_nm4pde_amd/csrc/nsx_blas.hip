@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void k_mgs(int n, int split, int gap, double *
     const int i0 = t + k * T;
     idx[k] = i0 < n ? i0 + (i0 >= split ? gap : 0) : -1;
     wv[k] = idx[k] >= 0 ? w[idx[k]] : 0.0;
-    vc[k] = idx[k] >= 0 ? V.v[0][idx[k]] : 0.0;
+    vc[k] = idx[k] >= 0 ? ld_stream<1>(V.v[0] + idx[k]) : 0.0;
     vn[k] = 0.0;
   }
   // consider: SolverGMRES' re-orthogonalisation test (every 5th inner iteration) needs |w| BEFORE the sweep: one more link
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void k_mgs(int n, int split, int gap, double *
     if (!pre && s + 1 < dim) {
       const double *__restrict__ vp = V.v[s + 1];
 #pragma unroll
-      for (int k = 0; k < E; ++k) vn[k] = idx[k] >= 0 ? vp[idx[k]] : 0.0;
+      for (int k = 0; k < E; ++k) vn[k] = idx[k] >= 0 ? ld_stream<1>(vp + idx[k]) : 0.0;
     }
     if (threadIdx.x == 0) {
       bc = first != GX_EMPTY ? first : gx_wait(total + ri, &lerr);
@@ -369,6 +369,280 @@ __global__ __launch_bounds__(256) void k_mgs(int n, int split, int gap, double *
     if (idx[k] >= 0) w[idx[k]] = wv[k];
 }
 
+// ---- the same sweep with M links per grid-wide exchange ---------------------------------------------------------------
+// The chain's coefficients are h_j = v_j . w_j with w_{j+1} = w_j - h_j v_j.  For the links j0 .. j0+M-1 of a block, by
+// linearity of the dot product (no orthogonality of the basis is assumed),
+//     h_j = v_j . (w_{j0} - sum_{j0 <= i < j} h_i v_i) = r_j - sum_{j0 <= i < j} (v_i . v_j) h_i ,   r_j = v_j . w_{j0} :
+// the M numbers r_j and the M (M-1) / 2 numbers v_i . v_j are sums over the SAME registers (the block's M basis vectors and
+// w_{j0} are held by the thread), so they travel in ONE exchange, workgroup 0 solves the unit lower-triangular M x M system
+// and hands out h_{j0..j0+M-1}, and every thread applies w += (-h_j) v_j for j ascending exactly as the chain does.  The
+// entries of w see the chain's operations in the chain's order; the coefficients differ from the chain's by the rounding
+// of the dot products only (identical in exact arithmetic, whatever the basis).  A sweep of `dim` links costs
+// ceil(dim / M) + 1 exchanges instead of dim + 1 (tools/exchange_bench.hip: 2.4 - 3.7 us each).  M = 1 is k_mgs.
+// Mailboxes: value-major, box[(x * NV + v) * nwg + wg] for exchange x, so workgroup 0 reads them coalesced.
+constexpr int MGS_BLK_TOT = 64;  // words reserved for the totals of a region ((M + 1) per exchange)
+constexpr size_t MGS_BLK_REGION = 57344 + MGS_BLK_TOT;  // (ceil(28 / M) + 1) * NV * 512 words for M <= 5, + the totals
+
+#ifdef NSX_MGS_TRACE  // development only (tools/mgs_bench.hip): wall-clock stamps of workgroup 0 and of the last workgroup
+__device__ unsigned long long *g_mgs_trace = nullptr;
+#define MGS_STAMP()                                                                                         \
+  do {                                                                                                      \
+    if (g_mgs_trace && threadIdx.x == 0 && (wg == 0 || wg == nwg - 1) && n_stamp < 64)                       \
+      g_mgs_trace[(wg == 0 ? 0 : 64) + n_stamp++] = wall_clock64();                                          \
+  } while (0)
+#else
+#define MGS_STAMP() \
+  do {              \
+  } while (0)
+#endif
+
+template <int E, int M, bool PF>
+__global__ __launch_bounds__(256) void k_mgs_blk(int n, int split, int gap, double *__restrict__ w, MgsArgs V, int dim, unsigned long long *box,
+                                                 unsigned long long *box_next, int reset_words, double *__restrict__ scal_out, int *err_host,
+                                                 unsigned long long *tail, int normalize, int consider, double *pub_vals,
+                                                 unsigned long long *pub_flag, unsigned long long seq) {
+  constexpr int NP = M * (M - 1) / 2, NV = M + NP + 1;  // r_0..r_{M-1}, pairs (i < j) at M + j (j - 1) / 2 + i, |w|^2 before the sweep
+  __shared__ double sh[4][NV];
+  __shared__ double bc[M + 1];
+  __shared__ int s_err;
+  __shared__ double tots[MGS_STEPS + 2];
+  const int nwg = gridDim.x, wg = blockIdx.x, T = nwg * 256, t = wg * 256 + threadIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  [[maybe_unused]] int n_stamp = 0;
+  MGS_STAMP();
+  if (threadIdx.x == 0) s_err = 0;
+  unsigned long long *total = box + (MGS_BLK_REGION - MGS_BLK_TOT), *total_next = box_next + (MGS_BLK_REGION - MGS_BLK_TOT);
+  for (int q = t; q < reset_words; q += T) box_next[q] = GX_EMPTY;
+  if (wg == 0 && threadIdx.x < MGS_BLK_TOT) total_next[threadIdx.x] = GX_EMPTY;
+  double wv[E], vb[M][E], vn[PF ? M : 1][PF ? E : 1];
+  int idx[E];
+#pragma unroll
+  for (int k = 0; k < E; ++k) {
+    const int i0 = t + k * T;
+    idx[k] = i0 < n ? i0 + (i0 >= split ? gap : 0) : -1;
+    wv[k] = idx[k] >= 0 ? w[idx[k]] : 0.0;
+  }
+  auto load_block = [&](double (&dst)[M][E], int j0) {
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      if (j0 + i < dim) {
+        const double *__restrict__ vp = V.v[j0 + i];
+#pragma unroll
+        for (int k = 0; k < E; ++k) dst[i][k] = idx[k] >= 0 ? ld_stream<1>(vp + idx[k]) : 0.0;
+      } else {
+#pragma unroll
+        for (int k = 0; k < E; ++k) dst[i][k] = 0.0;
+      }
+    }
+  };
+  load_block(vb, 0);
+  const int nblk = (dim + M - 1) / M;
+  double norm0_sq = 0.0;
+  int lerr = 0;
+  bool dead = false;
+  for (int x = 0; x <= nblk; ++x) {
+    const bool last = x == nblk;
+    const int j0 = x * M, mb = last ? 0 : (dim - j0 < M ? dim - j0 : M);
+    const bool pre = x == 0 && consider;
+    // which of the NV values this exchange carries (wave-uniform)
+    unsigned int used = last ? 1u : ((1u << mb) - 1u) | (((1u << (mb * (mb - 1) / 2)) - 1u) << M) | (pre ? 1u << (NV - 1) : 0u);
+    double acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = 0.0;
+    if (last) {
+#pragma unroll
+      for (int k = 0; k < E; ++k) acc[0] += wv[k] * wv[k];
+    } else {
+#pragma unroll
+      for (int i = 0; i < M; ++i)
+        if (i < mb) {
+#pragma unroll
+          for (int k = 0; k < E; ++k) acc[i] += wv[k] * vb[i][k];
+#pragma unroll
+          for (int i2 = 0; i2 < i; ++i2) {
+#pragma unroll
+            for (int k = 0; k < E; ++k) acc[M + i * (i - 1) / 2 + i2] += vb[i2][k] * vb[i][k];
+          }
+        }
+      if (pre) {
+#pragma unroll
+        for (int k = 0; k < E; ++k) acc[NV - 1] += wv[k] * wv[k];
+      }
+    }
+    // fixed-order sums over the workgroup, one barrier for all values
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+      if (used >> v & 1u) {
+        const double s = gx_wave_sum(acc[v]);
+        if (lane == 0) sh[wave][v] = s;
+      }
+    __syncthreads();
+    MGS_STAMP();  // local sums done (the block's loads have arrived)
+    unsigned long long *xbox = box + (size_t)x * NV * nwg;
+    if (threadIdx.x < NV && (used >> threadIdx.x & 1u)) {
+      const int v = threadIdx.x;
+      gx_post(xbox + (size_t)v * nwg + wg, (sh[0][v] + sh[1][v]) + (sh[2][v] + sh[3][v]));
+    }
+    unsigned long long *xtot = total + x * (M + 1);
+    if (wg == 0) {
+      __syncthreads();  // sh is reused below
+      double a[NV];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) a[v] = 0.0;
+      for (int q = threadIdx.x; q < nwg; q += 256) {
+        unsigned long long b[NV], t0 = 0;
+        for (unsigned int spin = 1;; ++spin) {
+          bool all = true;
+#pragma unroll
+          for (int v = 0; v < NV; ++v)
+            if (used >> v & 1u) b[v] = gx_load(xbox + (size_t)v * nwg + q);
+#pragma unroll
+          for (int v = 0; v < NV; ++v)
+            if (used >> v & 1u) all = all && b[v] != GX_EMPTY;
+          if (all) break;
+          __builtin_amdgcn_s_sleep(1);
+          if ((spin & 255u) == 0) {
+            const unsigned long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            else if (now - t0 > GX_TIMEOUT_TICKS) {
+              lerr = 1;
+              break;
+            }
+          }
+        }
+        if (lerr) break;
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+          if (used >> v & 1u) a[v] += __longlong_as_double((long long)b[v]);
+      }
+      if (lerr) s_err = 1;
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+        if (used >> v & 1u) {
+          const double s = gx_wave_sum(a[v]);
+          if (lane == 0) sh[wave][v] = s;
+        }
+      __syncthreads();
+      // a coefficient built on a timed-out mailbox must never go out: the others then time out as well and nobody writes w
+      if (threadIdx.x == 0 && !s_err) {
+        double tv[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) tv[v] = (used >> v & 1u) ? (sh[0][v] + sh[1][v]) + (sh[2][v] + sh[3][v]) : 0.0;
+        if (last) {
+          scal_out[dim] = tv[0];
+          gx_post(xtot, tv[0]);
+          tots[dim] = tv[0];
+        } else {
+          double hc[M];
+#pragma unroll
+          for (int j = 0; j < M; ++j) {
+            double s = tv[j];
+#pragma unroll
+            for (int i = 0; i < j; ++i) s -= tv[M + j * (j - 1) / 2 + i] * hc[i];
+            hc[j] = s;
+            if (j < mb) {
+              scal_out[j0 + j] = s;
+              gx_post(xtot + j, s);
+              tots[j0 + j] = s;
+            }
+          }
+          if (pre) {
+            scal_out[dim + 1] = tv[NV - 1];
+            gx_post(xtot + M, tv[NV - 1]);
+            tots[dim + 1] = tv[NV - 1];
+          }
+        }
+      }
+    }
+    MGS_STAMP();  // posted (workgroup 0: coefficients out)
+    // the next block of basis vectors is fetched while the sums are exchanged (behind this workgroup's post and first poll,
+    // see k_mgs)
+    const int nw = last ? 1 : mb + (pre ? 1 : 0);  // words to pick up: h of the block (+ |w|^2 before the sweep in word M)
+    unsigned long long first = GX_EMPTY;
+    const int myword = (int)threadIdx.x < (last ? 1 : mb) ? (int)threadIdx.x : M;
+    if ((int)threadIdx.x < nw) first = gx_load(xtot + myword);
+    if constexpr (PF) {
+      if (!last && x + 1 < nblk) load_block(vn, j0 + M);
+    }
+    if ((int)threadIdx.x < nw) {
+      const unsigned long long b = first != GX_EMPTY ? first : gx_wait(xtot + myword, &lerr);
+      if (lerr) s_err = 1;
+      bc[myword] = __longlong_as_double((long long)b);
+    }
+    __syncthreads();
+    MGS_STAMP();  // coefficients picked up
+    dead = s_err != 0;
+    if (dead) break;
+    if (last) {
+      if (normalize) {  // vv *= 1. / s with s = sqrt(|vv|^2), skipped for s == 0 (SolverGMRES)
+        const double nrm = sqrt(bc[0]);
+        // no normalisation if the test asks for a second sweep: s <= 10 |vv_start| sqrt(eps), sqrt(eps) = 2^-26
+        const bool second_sweep = consider && !(nrm > 10. * sqrt(norm0_sq) * 1.4901161193847656e-08);
+        if (nrm != 0.0 && !second_sweep) {
+          const double inv = 1. / nrm;
+#pragma unroll
+          for (int k = 0; k < E; ++k) wv[k] = inv * wv[k];
+        }
+      }
+    } else {
+      if (pre) norm0_sq = bc[M];
+#pragma unroll
+      for (int i = 0; i < M; ++i)
+        if (i < mb) {
+          const double alpha = -1.0 * bc[i];
+#pragma unroll
+          for (int k = 0; k < E; ++k) wv[k] += alpha * vb[i][k];
+        }
+      if (x + 1 < nblk) {
+        if constexpr (PF) {
+#pragma unroll
+          for (int i = 0; i < M; ++i)
+#pragma unroll
+            for (int k = 0; k < E; ++k) vb[i][k] = vn[i][k];
+        } else {
+          load_block(vb, j0 + M);
+        }
+      }
+    }
+    __syncthreads();  // bc and sh are rewritten by the next exchange
+  }
+  if (dead) {
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(err_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (wg == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(pub_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    return;
+  }
+  if (wg == 0) {
+    if ((int)threadIdx.x <= dim + (consider ? 1 : 0)) __hip_atomic_store(pub_vals + threadIdx.x, tots[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(pub_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (threadIdx.x == 0) tail[wg] = seq;  // this workgroup commits its part of w
+#pragma unroll
+  for (int k = 0; k < E; ++k)
+    if (idx[k] >= 0) w[idx[k]] = wv[k];
+  MGS_STAMP();
+}
+
+template <int M>
+static const void *mgs_blk_fn(int e) {
+  return e <= 8 ? (const void *)k_mgs_blk<8, M, true> : e <= 10 ? (const void *)k_mgs_blk<10, M, true> : (const void *)k_mgs_blk<20, M, false>;
+}
+static const void *mgs_fn(int m, int e) {
+  switch (m) {
+    case 2: return mgs_blk_fn<2>(e);
+    case 3: return mgs_blk_fn<3>(e);
+    case 4: return mgs_blk_fn<4>(e);
+    case 5: return mgs_blk_fn<5>(e);
+    default: return e <= 10 ? (const void *)k_mgs<10> : (const void *)k_mgs<20>;
+  }
+}
+
 static void mgs_setup(nsx_handle *h) {
   if (h->mgs_box.p || h->mgs_disabled) return;
   h->mgs_max_wg = 0;
@@ -376,22 +650,24 @@ static void mgs_setup(nsx_handle *h) {
     h->mgs_disabled = true;
     return;
   }
-  int cus = 0, per_cu = 0;
+  // links per exchange: 1 = deal.II's chain link by link (k_mgs), 2..5 = k_mgs_blk
+  h->mgs_links = getenv("NSX_MGS_LINKS") ? std::max(1, std::min(5, atoi(getenv("NSX_MGS_LINKS")))) : 2;
+  int cus = 0;
   HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->prm.device));
-  int per_cu20 = 0;
-  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mgs<10>, 256, 0));
-  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu20, k_mgs<20>, 256, 0));
-  h->mgs_box.alloc(2 * MGS_REGION + MGS_TAIL);
-  HIP_CHECK(hipMemsetAsync(h->mgs_box.p, 0xff, 2 * MGS_REGION * sizeof(unsigned long long), h->stream));
-  HIP_CHECK(hipMemsetAsync(h->mgs_box.p + 2 * MGS_REGION, 0, MGS_TAIL * sizeof(unsigned long long), h->stream));
-  h->mgs_max_wg = std::min(MGS_MAX_WG, per_cu * cus);
-  h->mgs_max_wg20 = std::min(MGS_MAX_WG, per_cu20 * cus);
-  if (getenv("NSX_MGS_MAXWG")) {
-    h->mgs_max_wg = std::max(1, std::min(h->mgs_max_wg, atoi(getenv("NSX_MGS_MAXWG"))));
-    h->mgs_max_wg20 = std::max(1, std::min(h->mgs_max_wg20, atoi(getenv("NSX_MGS_MAXWG"))));
+  const size_t region = std::max(MGS_REGION, MGS_BLK_REGION);
+  h->mgs_box.alloc(2 * region + MGS_TAIL);
+  HIP_CHECK(hipMemsetAsync(h->mgs_box.p, 0xff, 2 * region * sizeof(unsigned long long), h->stream));
+  HIP_CHECK(hipMemsetAsync(h->mgs_box.p + 2 * region, 0, MGS_TAIL * sizeof(unsigned long long), h->stream));
+  const int es[3] = {8, 10, 20};
+  for (int k = 0; k < 3; ++k) {
+    int per_cu = 0;
+    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mgs_fn(h->mgs_links, es[k]), 256, 0));
+    h->mgs_max_wg_e[k] = std::min(MGS_MAX_WG, per_cu * cus);
+    if (getenv("NSX_MGS_MAXWG")) h->mgs_max_wg_e[k] = std::max(1, std::min(h->mgs_max_wg_e[k], atoi(getenv("NSX_MGS_MAXWG"))));
+    if (getenv("NSX_DEBUG")) fprintf(stderr, "[nsx] mgs sweep (%d links per exchange, %d entries per thread): %d CUs x %d resident workgroups\n", h->mgs_links, es[k], cus, per_cu);
   }
+  h->mgs_max_wg = h->mgs_max_wg_e[1];
   h->mgs_coop = getenv("NSX_MGS_COOP") && atoi(getenv("NSX_MGS_COOP")) != 0;
-  if (getenv("NSX_DEBUG")) fprintf(stderr, "[nsx] mgs sweep: %d CUs x %d resident workgroups, grid <= %d\n", cus, per_cu, h->mgs_max_wg);
 }
 
 void wait_published(nsx_handle *h, unsigned long long seq) {
@@ -413,12 +689,13 @@ void wait_published(nsx_handle *h, unsigned long long seq) {
 static unsigned int mgs_recover(nsx_handle *h, unsigned long long failed_seq) {
   HIP_CHECK(hipStreamSynchronize(h->stream));
   std::vector<unsigned long long> tail(MGS_TAIL, 0);
-  HIP_CHECK(hipMemcpy(tail.data(), h->mgs_box.p + 2 * MGS_REGION, MGS_TAIL * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-  HIP_CHECK(hipMemsetAsync(h->mgs_box.p, 0xff, 2 * MGS_REGION * sizeof(unsigned long long), h->stream));
-  HIP_CHECK(hipMemsetAsync(h->mgs_box.p + 2 * MGS_REGION, 0, MGS_TAIL * sizeof(unsigned long long), h->stream));
+  const size_t region = std::max(MGS_REGION, MGS_BLK_REGION);
+  HIP_CHECK(hipMemcpy(tail.data(), h->mgs_box.p + 2 * region, MGS_TAIL * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  HIP_CHECK(hipMemsetAsync(h->mgs_box.p, 0xff, 2 * region * sizeof(unsigned long long), h->stream));
+  HIP_CHECK(hipMemsetAsync(h->mgs_box.p + 2 * region, 0, MGS_TAIL * sizeof(unsigned long long), h->stream));
   *(volatile int *)(h->pub_host + N_SLOTS + 2) = 0;
   h->mgs_used_wg[0] = h->mgs_used_wg[1] = h->mgs_used_steps[0] = h->mgs_used_steps[1] = 0;
-  h->mgs_max_wg = h->mgs_max_wg20 = 0;
+  h->mgs_max_wg = h->mgs_max_wg_e[0] = h->mgs_max_wg_e[1] = h->mgs_max_wg_e[2] = 0;
   h->mgs_disabled = true;
   unsigned int committed = 0;
   for (unsigned long long v : tail) committed += v == failed_seq;
@@ -439,11 +716,14 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
            const std::function<void()> *after_launch, bool consider) {
   const int n = sp.n;
   if (!h->comm) mgs_setup(h);
-  int nwg = std::max(1, std::min(h->mgs_max_wg, cdiv(n, 256 * 4)));
-  int per_thread = cdiv(n, (int64_t)nwg * 256);
-  if (per_thread > 10) {  // the 20-entries-per-thread instantiation needs more registers: its own residency limit
-    nwg = std::max(1, std::min(h->mgs_max_wg20, cdiv(n, 256 * 4)));
+  // entries per thread: the smallest instantiation (8, 10, 20) whose resident grid covers the vector
+  int nwg = 1, per_thread = 1 << 30, e_inst = 0;
+  for (int k = 0; k < 3 && h->mgs_max_wg; ++k) {
+    static const int es[3] = {8, 10, 20};
+    nwg = std::max(1, std::min(h->mgs_max_wg_e[k], cdiv(n, 256 * 4)));
     per_thread = cdiv(n, (int64_t)nwg * 256);
+    e_inst = es[k];
+    if (per_thread <= es[k]) break;
   }
   if (h->comm || h->mgs_max_wg == 0 || dim + 2 > MGS_STEPS || per_thread > 20) {
     // one launch per link: the distributed solve needs an all-reduce after every dot product
@@ -456,25 +736,38 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
     MgsArgs V;
     for (int i = 0; i < dim; ++i) V.v[i] = vs[i];
     for (int i = dim; i < MGS_STEPS; ++i) V.v[i] = nullptr;
+    const size_t region = std::max(MGS_REGION, MGS_BLK_REGION);
+    const int M = h->mgs_links;
     int n_ = n, split = sp.split, gap = sp.gap, dim_ = dim, norm_ = normalize ? 1 : 0, consider_ = consider ? 1 : 0;
-    unsigned long long *box = h->mgs_box.p + (size_t)h->mgs_parity * MGS_REGION, *box_next = h->mgs_box.p + (size_t)(1 - h->mgs_parity) * MGS_REGION;
+    unsigned long long *box = h->mgs_box.p + (size_t)h->mgs_parity * region, *box_next = h->mgs_box.p + (size_t)(1 - h->mgs_parity) * region;
     double *sout = h->scal.p + slot0, *pub_vals = h->pub_dev + slot0;
     unsigned long long *pub_flag = (unsigned long long *)(h->pub_dev + N_SLOTS), seq_ = seq;
     int *err = (int *)(h->pub_dev + N_SLOTS + 2);  // mapped host word
-    unsigned long long *tail = h->mgs_box.p + 2 * MGS_REGION;
+    unsigned long long *tail = h->mgs_box.p + 2 * region;
     int reset_wg = h->mgs_used_wg[1 - h->mgs_parity], reset_steps = h->mgs_used_steps[1 - h->mgs_parity];
-    void *args[] = {&n_, &split, &gap, &w, &V, &dim_, &box, &box_next, &reset_wg, &reset_steps, &sout, &err, &tail, &norm_, &consider_, &pub_vals, &pub_flag, &seq_};
     // Co-residency: the grid never exceeds what the device holds at once (mgs_setup), the stream is in-order and normally nothing
     // else runs on the device, so a plain launch places every workgroup at once.  hipLaunchCooperativeKernel (NSX_MGS_COOP=1) adds
     // a launch-time size check and ~20 us of cross-queue synchronisation per launch, but no residency guarantee beyond that
     // (/opt/skills/guides/MI355X_MICROARCH.md, "Residency and cooperative launch").  What makes the sweep safe is the bounded wait:
     // should a workgroup be missing (another stream or process holds compute units), the kernel ends without writing w and the
     // sweep is redone by the launch-per-link chain below.
-    const void *fn = per_thread <= 10 ? (const void *)k_mgs<10> : (const void *)k_mgs<20>;
-    if (h->mgs_coop) HIP_CHECK(hipLaunchCooperativeKernel(fn, dim3(nwg), dim3(256), args, 0, h->stream));
-    else HIP_CHECK(hipLaunchKernel(fn, dim3(nwg), dim3(256), args, 0, h->stream));
-    h->mgs_used_wg[h->mgs_parity] = nwg;
-    h->mgs_used_steps[h->mgs_parity] = dim + 2;
+    const void *fn = mgs_fn(M, e_inst);
+    if (M == 1) {
+      void *args[] = {&n_, &split, &gap, &w, &V, &dim_, &box, &box_next, &reset_wg, &reset_steps, &sout, &err, &tail, &norm_, &consider_, &pub_vals, &pub_flag, &seq_};
+      if (h->mgs_coop) HIP_CHECK(hipLaunchCooperativeKernel(fn, dim3(nwg), dim3(256), args, 0, h->stream));
+      else HIP_CHECK(hipLaunchKernel(fn, dim3(nwg), dim3(256), args, 0, h->stream));
+      h->mgs_used_wg[h->mgs_parity] = nwg;
+      h->mgs_used_steps[h->mgs_parity] = dim + 2;
+    } else {
+      // k_mgs_blk: the region is a flat array of (exchanges x values x workgroups) words; "steps" counts words, "wg" is 1
+      int reset_words = reset_wg * reset_steps;
+      void *args[] = {&n_, &split, &gap, &w, &V, &dim_, &box, &box_next, &reset_words, &sout, &err, &tail, &norm_, &consider_, &pub_vals, &pub_flag, &seq_};
+      if (h->mgs_coop) HIP_CHECK(hipLaunchCooperativeKernel(fn, dim3(nwg), dim3(256), args, 0, h->stream));
+      else HIP_CHECK(hipLaunchKernel(fn, dim3(nwg), dim3(256), args, 0, h->stream));
+      const int nv = M + M * (M - 1) / 2 + 1;
+      h->mgs_used_wg[h->mgs_parity] = 1;
+      h->mgs_used_steps[h->mgs_parity] = (cdiv(dim, M) + 1) * nv * nwg;
+    }
     h->mgs_used_wg[1 - h->mgs_parity] = h->mgs_used_steps[1 - h->mgs_parity] = 0;
     h->mgs_parity ^= 1;
     for (int i = 0; i <= dim + 1; ++i) h->slot_nb[slot0 + i] = 0;

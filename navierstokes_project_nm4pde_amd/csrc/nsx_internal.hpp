@@ -25,6 +25,21 @@
 #include "../../include/nsx.h"
 #include "../host/graph.hpp"
 
+// Cache policy (compile time, -DNSX_NT=mask): non-temporal loads for 1 = the Krylov basis in the Gram-Schmidt sweep,
+// 2 = the matrix stream of the LDS-staged SpMV, 4 = the factor stream of the packed triangular solve.  An inner GMRES
+// iteration on F streams F (126 MB), the ILU factors (130 MB) and the basis (17 - 125 MB) once each: more than the 256-MiB
+// Infinity Cache holds, so with default-policy loads every stream evicts the next one's lines.  Measured per mask
+// (tools/nt_sweep.sh, us per launch SpMV / triangular solve / sweep): 0: 34.2 / 34.4 / 35.2; 1: 30.6 / 32.8 / 35.7;
+// 4: 30.7 / 35.1 / 32.8; 2: 39.5 / 33.4 / 33.0 (the 2-byte index stream does not like nt); 6, 7: worse.
+#ifndef NSX_NT
+#define NSX_NT 1
+#endif
+template <int BIT, class T>
+__device__ __forceinline__ T ld_stream(const T *p) {
+  if constexpr ((NSX_NT & BIT) != 0) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+
 namespace nsx {
 
 struct Error {
@@ -246,7 +261,8 @@ struct nsx_handle {
   bool sched_dirty = true;  // the ILU schedules do not match the current rank tables yet
   int mgs_used_wg[2] = {0, 0}, mgs_used_steps[2] = {0, 0};  // what the last launch on each region filled
   int mgs_parity = 0, mgs_max_wg = 0;  // mgs_max_wg = 0: the launch-per-link chain is used
-  int mgs_max_wg20 = 0;                // the same limit for the 20-entries-per-thread instantiation
+  int mgs_max_wg_e[3] = {0, 0, 0};     // resident-grid limit of the 8 / 10 / 20 entries-per-thread instantiations
+  int mgs_links = 2;                   // links of the add_and_dot chain per grid-wide exchange (NSX_MGS_LINKS; 1 = k_mgs)
   bool mgs_coop = false, mgs_disabled = false;
   bool mgs_redo_ahead = false;         // a sweep fell back to the chain after work depending on its w had been enqueued
   // persistent Schur-complement CG (nsx_cg.hip: k_cg_schur): mailbox regions, work vectors (d double-buffered, h)

@@ -172,8 +172,8 @@ __global__ __launch_bounds__(256) void k_spmv_blocked(int n_rows, int n_chunks, 
     for (int k = 0; k < U; ++k) {
       const int q = p0 + k * W;
       const bool ok = q < e;
-      va[k] = ok ? av[q] : 0.0;
-      vl[k] = ok ? (int)lidx[q] : 0;
+      va[k] = ok ? ld_stream<2>(av + q) : 0.0;
+      vl[k] = ok ? (int)ld_stream<2>(lidx + q) : 0;
     }
   };
   auto consume = [&](int rw, const double (&va)[U], const int (&vl)[U]) {
@@ -996,8 +996,8 @@ __device__ __forceinline__ void packed_sweep(int sa, int sb, const int32_t *__re
   _Pragma("unroll") for (int k = 0; k < PF; ++k) {              \
     const int s_ = (S0) + k;                                    \
     const bool ok_ = s_ < sb;                                   \
-    V[k] = ok_ ? val[(size_t)s_ * 64 + lane] : 0.0;             \
-    M[k] = ok_ ? meta[(size_t)s_ * 64 + lane] : 0;              \
+    V[k] = ok_ ? ld_stream<4>(val + (size_t)s_ * 64 + lane) : 0.0; \
+    M[k] = ok_ ? ld_stream<4>(meta + (size_t)s_ * 64 + lane) : 0;  \
   }
 #define NSX_USE(V, M, S0)                                       \
   _Pragma("unroll") for (int k = 0; k < PF; ++k)                \
