@@ -187,6 +187,11 @@ typedef int (*nsx_allreduce_fn)(void *ctx, double *buf, int count);
 typedef int (*nsx_exchange_fn)(void *ctx, int n, const int *ranks, const double *const *send, const int *send_count,
                                double *const *recv, const int *recv_count);
 int nsx_comm_init_callbacks(nsx_handle *h, int rank, int world, nsx_allreduce_fn allreduce, nsx_exchange_fn exchange, void *ctx);
+/* Collectives issued by this handle since the communicator was set: counts[0] all-reduces (the MPI_Allreduce behind Epetra's
+ * Dot / Norm2, reference Preconditioners.hpp:157,179,371,388,403 and every SolverGMRES / SolverCG iteration), counts[1] ghost
+ * exchanges (the Epetra_Import of every vmult).  The orthogonalisation of a Krylov vector costs two all-reduces (csrc/nsx_blas.hip,
+ * mgs_lowsync) where the reference pays one per link of the add_and_dot chain. */
+int nsx_comm_counters(const nsx_handle *h, long long counts[2]);
 /* Distributed mesh, replaces nsx_set_mesh for world > 1.  cell_dofs keep the GLOBAL deal.II numbering; gpu_u_ptr /
  * gpu_p_ptr [world+1] are the P2 / P1 node ranges owned by each rank (locally_owned_dofs per block, reference
  * NavierStokes3D.cpp:71-87).  Cells: first the n_cells_layer1 cells that touch an owned P2 node (every owned row is

@@ -711,9 +711,137 @@ static void mgs_chain(nsx_handle *h, Span sp, double *w, int dim, double *const 
   read_scalars(h, slot0, dim + 1 + (consider ? 1 : 0), out);
 }
 
+// ---- the sweep with TWO collectives (distributed runs) ------------------------------------------------------------------
+// With a communicator every link of the chain is a launch plus an all-reduce (dim + 1 collectives per sweep, the reference
+// pays one MPI_Allreduce per link as well).  The same linearity that k_mgs_blk uses for M links holds for all of them:
+//     h_j = v_j . w - sum_{i < j} (v_i . v_j) h_i ,
+// so one pass computes r_j = v_j . w for every j and the new row of the basis' Gram matrix (v_{dim-1} . v_i, i < dim - 1; the
+// older rows were computed by the earlier sweeps of this GMRES cycle and are kept on the device), ONE all-reduce sums them over
+// the ranks, every rank solves the same unit lower-triangular system, and a second pass applies w += (-h_j) v_j for j ascending
+// (the chain's operations on every entry, in the chain's order) and leaves the partial sums of |w|^2 for the second all-reduce.
+// No orthogonality of the basis is assumed: in exact arithmetic the coefficients ARE the chain's.
+constexpr int LS_C = 8;       // basis vectors per pass of the dot kernel
+constexpr int LS_VALS = 64;   // r_j at j, Gram row at 32 + i, |w|^2 before the sweep at 63
+constexpr int LS_BLOCKS = 256;
+
+__global__ __launch_bounds__(256) void k_ls_dots(int n, int split, int gap, const double *__restrict__ w, MgsArgs V, int dim, double *__restrict__ partial) {
+  __shared__ double sh[4][2 * LS_C + 1];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const double *__restrict__ vl = V.v[dim - 1];
+  for (int c0 = 0; c0 < dim; c0 += LS_C) {
+    double ar[LS_C], ag[LS_C], aw = 0.0;
+#pragma unroll
+    for (int k = 0; k < LS_C; ++k) ar[k] = ag[k] = 0.0;
+    for (int i0 = blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += gridDim.x * 256) {
+      const int i = i0 + (i0 >= split ? gap : 0);
+      const double wi = w[i], li = vl[i];
+#pragma unroll
+      for (int k = 0; k < LS_C; ++k)
+        if (c0 + k < dim) {
+          const double vk = V.v[c0 + k][i];
+          ar[k] += wi * vk;
+          ag[k] += li * vk;
+        }
+      aw += wi * wi;
+    }
+#pragma unroll
+    for (int k = 0; k < LS_C; ++k) {
+      const double a = gx_wave_sum(ar[k]), b = gx_wave_sum(ag[k]);
+      if (lane == 0) sh[wave][k] = a, sh[wave][LS_C + k] = b;
+    }
+    {
+      const double a = gx_wave_sum(aw);
+      if (lane == 0) sh[wave][2 * LS_C] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * LS_C + 1) {
+      const int q = threadIdx.x;
+      const double tot = (sh[0][q] + sh[1][q]) + (sh[2][q] + sh[3][q]);
+      const int j = c0 + (q < LS_C ? q : q - LS_C);
+      if (q < LS_C) {
+        if (j < dim) partial[(size_t)j * LS_BLOCKS + blockIdx.x] = tot;
+      } else if (q < 2 * LS_C) {
+        if (j < dim - 1) partial[(size_t)(32 + j) * LS_BLOCKS + blockIdx.x] = tot;
+      } else if (c0 == 0) {
+        partial[(size_t)63 * LS_BLOCKS + blockIdx.x] = tot;
+      }
+    }
+    __syncthreads();
+  }
+}
+// vals[v] = fixed-order sum of the LS_BLOCKS partial sums of value v (one workgroup per value; unused values become 0)
+__global__ __launch_bounds__(256) void k_ls_finalize(int dim, const double *__restrict__ partial, double *__restrict__ vals) {
+  __shared__ double sh[4];
+  const int v = blockIdx.x;
+  const bool used = v < dim || (v >= 32 && v < 32 + dim - 1) || v == 63;
+  const double a = used ? partial[(size_t)v * LS_BLOCKS + threadIdx.x] : 0.0;
+  const double t = gx_block_sum(a, sh);
+  if (threadIdx.x == 0) vals[v] = t;
+}
+// every rank, from the same all-reduced numbers: the new Gram row, then h = (I + L)^-1 r by forward substitution
+__global__ __launch_bounds__(64) void k_ls_solve(int dim, int consider, const double *__restrict__ vals, double *__restrict__ gram, double *__restrict__ scal_out) {
+  __shared__ double G[32][33], hc[32];
+  const int t = threadIdx.x;
+  for (int i = t; i < dim - 1; i += 64) gram[(dim - 1) * 32 + i] = vals[32 + i];
+  __syncthreads();
+  for (int q = t; q < dim * 32; q += 64) G[q >> 5][q & 31] = (q & 31) < (q >> 5) ? gram[q] : 0.0;
+  __syncthreads();
+  if (t == 0) {
+    for (int j = 0; j < dim; ++j) {
+      double s = vals[j];
+      for (int i = 0; i < j; ++i) s -= G[j][i] * hc[i];
+      hc[j] = s;
+      scal_out[j] = s;
+    }
+    if (consider) scal_out[dim + 1] = vals[63];
+  }
+}
+// w += (-h_j) v_j, j ascending; partial sums of |w|^2
+__global__ __launch_bounds__(256) void k_ls_update(int n, int split, int gap, double *__restrict__ w, MgsArgs V, int dim, const double *__restrict__ coef,
+                                                   double *__restrict__ partial) {
+  __shared__ double hs[32], sh[5];
+  if ((int)threadIdx.x < dim) hs[threadIdx.x] = -1.0 * coef[threadIdx.x];
+  __syncthreads();
+  double acc = 0.0;
+  for (int i0 = blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += gridDim.x * 256) {
+    const int i = i0 + (i0 >= split ? gap : 0);
+    double wi = w[i];
+    for (int j = 0; j < dim; ++j) wi += hs[j] * V.v[j][i];
+    w[i] = wi;
+    acc += wi * wi;
+  }
+  const double t = block_sum_256(acc, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+static void mgs_lowsync(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int slot0, double *out, bool consider, double *gram) {
+  if (!h->ls_partial.p) {
+    h->ls_partial.alloc((size_t)LS_VALS * LS_BLOCKS);
+    h->ls_vals.alloc(LS_VALS);
+  }
+  MgsArgs V;
+  for (int i = 0; i < MGS_STEPS; ++i) V.v[i] = i < dim ? vs[i] : nullptr;
+  const int n = sp.n;
+  {
+    LaunchScope ls(h, "mgs_dots", 8.0 * n * (dim + 2.0 * cdiv(dim, LS_C)));
+    hipLaunchKernelGGL(k_ls_dots, dim3(LS_BLOCKS), dim3(256), 0, h->stream, n, sp.split, sp.gap, w, V, dim, h->ls_partial.p);
+    hipLaunchKernelGGL(k_ls_finalize, dim3(LS_VALS), dim3(256), 0, h->stream, dim, h->ls_partial.p, h->ls_vals.p);
+  }
+  comm_allreduce_partials(h, h->ls_vals.p, LS_VALS);  // collective 1: every r_j, the Gram row and |w|^2 before the sweep
+  hipLaunchKernelGGL(k_ls_solve, dim3(1), dim3(64), 0, h->stream, dim, consider ? 1 : 0, h->ls_vals.p, gram, h->scal.p + slot0);
+  for (int i = 0; i <= dim + 1; ++i) h->slot_nb[slot0 + i] = 0;
+  {
+    LaunchScope ls(h, "mgs_update", 8.0 * n * (dim + 2));
+    const int nb = red_blocks(h, n);
+    hipLaunchKernelGGL(k_ls_update, dim3(nb), dim3(256), 0, h->stream, n, sp.split, sp.gap, w, V, dim, h->scal.p + slot0, red_out(h, slot0 + dim, nb));
+    after_reduction(h, slot0 + dim, nb);  // collective 2: |w|^2
+  }
+  read_scalars(h, slot0, dim + 1 + (consider ? 1 : 0), out);
+}
+
 // out[0..dim) = h(i), out[dim] = |w|^2 after the sweep.  Returns true when w was also normalised (only if asked to).
 bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int slot0, bool normalize, double *out,
-           const std::function<void()> *after_launch, bool consider) {
+           const std::function<void()> *after_launch, bool consider, double *gram) {
   const int n = sp.n;
   if (!h->comm) mgs_setup(h);
   // entries per thread: the smallest instantiation (8, 10, 20) whose resident grid covers the vector
@@ -726,8 +854,11 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
     if (per_thread <= es[k]) break;
   }
   if (h->comm || h->mgs_max_wg == 0 || dim + 2 > MGS_STEPS || per_thread > 20) {
-    // one launch per link: the distributed solve needs an all-reduce after every dot product
-    mgs_chain(h, sp, w, dim, vs, slot0, out, consider);
+    // distributed solve: two collectives per sweep (mgs_lowsync); NSX_MGS_LOWSYNC=0: one launch + all-reduce per link, as the
+    // reference's MPI run does.  Without a Gram cache (or too many vectors for it) the chain as well.
+    if (h->ls_mode < 0) h->ls_mode = !(getenv("NSX_MGS_LOWSYNC") && atoi(getenv("NSX_MGS_LOWSYNC")) == 0);  // read once per handle
+    if (h->comm && h->ls_mode && gram && dim <= 31) mgs_lowsync(h, sp, w, dim, vs, slot0, out, consider, gram);
+    else mgs_chain(h, sp, w, dim, vs, slot0, out, consider);
     return false;
   }
   const unsigned long long seq = ++h->pub_seq;

@@ -33,6 +33,7 @@ struct Comm {
 void comm_allreduce_scalars(nsx_handle *h, int slot0, int count) {
   Comm *c = h->comm;
   if (!c || (c->world == 1 && !c->comm)) return;  // a 1-rank RCCL communicator still runs the collective (API self-test)
+  h->n_allreduce++;
   if (c->comm) {
     NCCL_CHECK(ncclAllReduce(h->scal.p + slot0, h->scal.p + slot0, count, ncclDouble, ncclSum, c->comm, h->stream));
   } else {
@@ -47,6 +48,7 @@ void comm_allreduce_scalars(nsx_handle *h, int slot0, int count) {
 void comm_allreduce_partials(nsx_handle *h, double *partials, int count) {
   Comm *c = h->comm;
   if (!c || (c->world == 1 && !c->comm)) return;
+  h->n_allreduce++;
   if (c->comm) {
     NCCL_CHECK(ncclAllReduce(partials, partials, count, ncclDouble, ncclSum, c->comm, h->stream));
   } else {
@@ -89,6 +91,7 @@ void comm_halo_begin(nsx_handle *h, HaloPlan &p, double *x, int ncomp) {
   }
   if (!p.ev_done) HIP_CHECK(hipEventCreateWithFlags(&p.ev_done, hipEventDisableTiming));
   const int n_send = p.send_ptr[nn];
+  h->n_halo++;
   HIP_CHECK(hipEventRecord(h->ev_ready, h->stream));
   HIP_CHECK(hipStreamWaitEvent(h->comm_stream, h->ev_ready, 0));
   launch_pack(h, p, x, ncomp, n_send, h->comm_stream);
@@ -190,6 +193,13 @@ int nsx_comm_init(nsx_handle *h, int rank, int world, const uint8_t id[128]) {
     h->err = e.msg;
     return e.code;
   }
+  return NSX_OK;
+}
+
+int nsx_comm_counters(const nsx_handle *h, long long counts[2]) {
+  if (!h || !counts) return NSX_ERR_ARG;
+  counts[0] = h->n_allreduce;
+  counts[1] = h->n_halo;
   return NSX_OK;
 }
 

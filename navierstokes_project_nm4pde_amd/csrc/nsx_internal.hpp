@@ -264,6 +264,10 @@ struct nsx_handle {
   int mgs_max_wg_e[3] = {0, 0, 0};     // resident-grid limit of the 8 / 10 / 20 entries-per-thread instantiations
   int mgs_links = 2;                   // links of the add_and_dot chain per grid-wide exchange (NSX_MGS_LINKS; 1 = k_mgs)
   bool mgs_coop = false, mgs_disabled = false;
+  // distributed sweep with two collectives (mgs_lowsync): partial sums / all-reduced values / one 32 x 32 Gram matrix per GMRES nesting level
+  nsx::DevBuf<double> ls_partial, ls_vals, ls_gram;
+  int gmres_depth = 0, ls_mode = -1;
+  long long n_allreduce = 0, n_halo = 0;  // collectives issued (nsx_comm_counters)
   bool mgs_redo_ahead = false;         // a sweep fell back to the chain after work depending on its w had been enqueued
   // persistent Schur-complement CG (nsx_cg.hip: k_cg_schur): mailbox regions, work vectors (d double-buffered, h)
   nsx::DevBuf<unsigned long long> cg_box;
@@ -380,7 +384,7 @@ void v_add_and_dot(nsx_handle *h, Span n, double *d, double a, int aslot, const 
 // after_launch (optional) runs between the launch and the wait for the coefficients, only when the sweep is one launch
 // AND normalises w: the caller may enqueue work that depends on the finished w alone.
 bool v_mgs(nsx_handle *h, Span n, double *w, int dim, double *const *vs, int slot0, bool normalize, double *out,
-           const std::function<void()> *after_launch = nullptr, bool consider = false);
+           const std::function<void()> *after_launch = nullptr, bool consider = false, double *gram = nullptr);
 // consider: also out[dim+1] = |w|^2 BEFORE the sweep (SolverGMRES' re-orthogonalisation test); a single-launch sweep then
 // normalises w only if the test does not ask for a second sweep.
 void v_axpy_multi(nsx_handle *h, Span n, double *x, int k, double *const *vs, const double *coef_host);

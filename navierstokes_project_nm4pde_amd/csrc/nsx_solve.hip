@@ -85,6 +85,22 @@ static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b,
     }
     return tmp[i]->p();
   };
+  // distributed runs: the Gram matrix of this solve's basis, kept on the device between its sweeps (mgs_lowsync); one per nesting
+  // level (the outer solve's preconditioner runs GMRES solves of its own between two outer sweeps)
+  struct Depth {
+    nsx_handle *h;
+    int d;
+    explicit Depth(nsx_handle *h_) : h(h_), d(h_->gmres_depth++) {}
+    ~Depth() { h->gmres_depth--; }
+  } depth(h);
+  double *gram = nullptr;
+  if (h->comm && depth.d < 4) {
+    if (!h->ls_gram.p) {
+      h->ls_gram.alloc(4 * 1024);
+      h->ls_gram.zero(h->stream);
+    }
+    gram = h->ls_gram.p + (size_t)depth.d * 1024;
+  }
   double H[N_TMP][N_TMP - 1];
   double gamma[N_TMP], ci[N_TMP - 1], si[N_TMP - 1], hh[N_TMP + 2], h2[N_TMP + 2];
   int accumulated = 0, state = 0, dim = 0;
@@ -140,7 +156,7 @@ static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b,
           }
         }
       };
-      bool normalized = v_mgs(h, n, vv, dim, basis, S_H, !re_orth, hh, &next_A, consider);
+      bool normalized = v_mgs(h, n, vv, dim, basis, S_H, !re_orth, hh, &next_A, consider, gram);
       if (h->mgs_redo_ahead) {  // the sweep fell back to the launch-per-link chain: A * vv was enqueued on an unfinished vv
         h->mgs_redo_ahead = false;
         ahead = 0;
@@ -151,7 +167,7 @@ static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b,
         if (!(s > 10. * norm_vv_start * std::sqrt(2.220446049250313e-16))) re_orth = true;
       }
       if (re_orth) {
-        normalized = v_mgs(h, n, vv, dim, basis, S_H2, true, h2);
+        normalized = v_mgs(h, n, vv, dim, basis, S_H2, true, h2, nullptr, false, gram);
         for (int i = 0; i < dim; ++i) hh[i] += h2[i];
         s = std::sqrt(h2[dim]);
       }

@@ -23,7 +23,7 @@ API = [
     "nsx_solve_time_step", "nsx_prec_initialize", "nsx_prec_vmult", "nsx_system_vmult", "nsx_ilu_apply",
     "nsx_export_block", "nsx_schur_nnz", "nsx_schur_get", "nsx_scalar_graph_nnz", "nsx_scalar_graph", "nsx_ilu_get",
     "nsx_profile_enable", "nsx_profile_reset", "nsx_profile_count", "nsx_profile_get", "nsx_comm_unique_id",
-    "nsx_comm_init", "nsx_comm_init_callbacks", "nsx_set_mesh_distributed", "nsx_set_force_faces", "nsx_compute_forces",
+    "nsx_comm_init", "nsx_comm_init_callbacks", "nsx_comm_counters", "nsx_set_mesh_distributed", "nsx_set_force_faces", "nsx_compute_forces",
 ]
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _f64p, C.c_int)
@@ -88,6 +88,7 @@ def lib():
     L.nsx_comm_unique_id.argtypes = [C.POINTER(C.c_uint8)]
     L.nsx_comm_init.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_uint8)]
     L.nsx_comm_init_callbacks.argtypes = [vp, C.c_int, C.c_int, ALLREDUCE_FN, EXCHANGE_FN, C.c_void_p]
+    L.nsx_comm_counters.argtypes = [vp, C.POINTER(C.c_longlong)]
     L.nsx_set_mesh_distributed.argtypes = [vp, C.c_int, C.c_int, C.c_int, _i32p, _f64p, C.c_int, C.c_int, C.c_int, C.c_int,
                                            _i32p, _i32p, C.c_int, _i32p, _i32p, _i32p, _i32p, _i32p]
     L.nsx_set_force_faces.argtypes = [vp, C.c_int, _i32p, _i32p, C.c_int, _f64p, _f64p, _f64p, _f64p]
@@ -186,6 +187,12 @@ class Nsx:
             dist.broadcast_object_list(box, src=0)
             ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
             self._ck(L.nsx_comm_init(self._h, rank, world, ident))
+
+    def comm_counters(self):
+        """(all-reduces, ghost exchanges) issued since the communicator was set"""
+        c = (C.c_longlong * 2)()
+        self._ck(self.L.nsx_comm_counters(self._h, c))
+        return int(c[0]), int(c[1])
 
     def comm_init_single(self):
         """1-rank RCCL communicator on this handle: every dot product then goes through ncclAllReduce (API self-test)."""

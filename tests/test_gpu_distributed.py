@@ -74,3 +74,38 @@ def test_rccl_single_rank_communicator_matches_plain_solve():
         dev.close()
     assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
     assert np.abs(out[0][2] - out[1][2]).max() < 1e-12 * np.abs(out[0][2]).max()
+
+
+def test_two_collectives_per_gram_schmidt_sweep_equal_the_chain():
+    """Distributed orthogonalisation: mgs_lowsync (all dots of a sweep and the new Gram row in ONE all-reduce, |w|^2 in a second)
+    against NSX_MGS_LOWSYNC=0 (one all-reduce per link of SolverGMRES' add_and_dot chain, what the reference's MPI run pays),
+    both through a 1-rank RCCL communicator so that the collectives really run.  Same iteration history, same solution (the
+    coefficients are the chain's by linearity of the dot product), and far fewer collectives."""
+    from navierstokes_project_nm4pde_amd import nsx
+    from navierstokes_project_nm4pde_amd.frontend import DoFs, Mesh, Tables
+    from navierstokes_project_nm4pde_amd.problem import InletVelocity, cylinder_boundary_values
+    mesh = Mesh.cylinder(3, 2).partition(1, 8)
+    dofs, tables = DoFs(mesh, "colour"), Tables(3)
+    out = []
+    for flag in ("0", "1"):
+        os.environ["NSX_MGS_LOWSYNC"] = flag
+        try:
+            dev = nsx.Nsx(dofs, tables, 1e-3, 2e-4)
+            dev.comm_init_single()
+            dev.set_solution(np.zeros(dofs.n_dofs))
+            dev.assemble(nsx.TEMAM)
+            dev.apply_boundary_values(*cylinder_boundary_values(dofs, InletVelocity(3), 2e-4))
+            dev.profile(True)
+            st = dev.solve_time_step(nsx.YOSIDA, tol_abs=1e-10, inner_rtol=1e-8)
+            out.append((st, dev.solution_owned.copy(), dev.comm_counters(), dev.profile_table()))
+            dev.close()
+        finally:
+            os.environ.pop("NSX_MGS_LOWSYNC", None)
+    (s0, x0, c0, t0), (s1, x1, c1, t1) = out
+    assert s0["status"] == 0 and s1["status"] == 0
+    for key in ("outer_iterations", "inner_F_iterations", "inner_S_iterations"):
+        assert abs(s0[key] - s1[key]) <= max(1, 0.02 * s0[key]), key
+    assert np.abs(x0 - x1).max() < 1e-9 * np.abs(x0).max()
+    assert t1.get("mgs_dots", {}).get("launches", 0) > 0 and t0.get("mgs_dots", {}).get("launches", 0) == 0
+    # the chain: about (dim + 1) all-reduces per Krylov vector; the two-collective sweep: 2 (+ the solver's own norms)
+    assert c1[0] < 0.5 * c0[0], (c0, c1)
