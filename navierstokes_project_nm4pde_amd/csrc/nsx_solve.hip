@@ -125,6 +125,7 @@ static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b,
     gamma[0] = rho;
     v_scale(h, n, v, 1. / rho);
     dim = 0;
+    double rho_before = 0.0;  // residual estimate one iteration earlier (0: none yet in this cycle)
     for (int inner = 0; inner < N_TMP - 2 && state == 0; ++inner) {
       ++accumulated;
       double *vv = vec(inner + 1);
@@ -145,9 +146,15 @@ static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b,
       // The sweep leaves the next basis vector complete; A * vv of the NEXT iteration is enqueued right behind it, so the
       // device does not idle while the coefficients travel to the host and the Givens rotations are updated.  Wasted
       // once per solve (the iteration that converges); p is a temporary.
+      // ... unless this iteration will probably be the last one: the residual after it is estimated from the last reduction factor
+      // (rho * rho / rho_before); a wrong "continues" costs one wasted operator + preconditioner application, a wrong
+      // "converges" one exposed host round trip, so the test leans towards not running ahead (NSX_AHEAD_MARGIN, default 2 x tol).
+      static const double ahead_margin = getenv("NSX_AHEAD_MARGIN") ? atof(getenv("NSX_AHEAD_MARGIN")) : 2.0;
+      const bool likely_last = rho_before > 0.0 && rho * std::min(1.0, rho / rho_before) <= ahead_margin * tol;
       const std::function<void()> next_A = [&]() {
-        if (inner + 1 < N_TMP - 2) {
-          if (plain_P) {  // inner solves on F: operator AND preconditioner of the next iteration are plain kernels that depend on vv alone
+        if (inner + 1 < N_TMP - 2 && !likely_last) {
+          static const int ahead_mode = getenv("NSX_AHEAD_MODE") ? atoi(getenv("NSX_AHEAD_MODE")) : 2;
+          if (plain_P && ahead_mode == 2) {  // inner solves on F: operator AND preconditioner of the next iteration are plain kernels that depend on vv alone
             apply_AP(vec(inner + 2), vv);
             ahead = 2;
           } else {   // the outer solve's preconditioner runs Krylov solves of its own (host round trips, the same scalar slots): only A
@@ -186,6 +193,7 @@ static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b,
       gamma[inner + 1] = -si[inner] * gamma[inner];
       gamma[inner] *= ci[inner];
       for (int i = 0; i < dim; ++i) H[i][inner] = hh[i];
+      rho_before = rho;
       rho = std::fabs(gamma[dim]);
       res.last = rho;
       state = sc_check(accumulated, rho, tol, maxiter);
