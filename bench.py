@@ -271,9 +271,11 @@ def summarise_kernels(table, prof_stats):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20,
-                    help="timed time steps (GMRES(28) needs a restart in some steps and not in others: 20 - 28 or 45 - 55 outer "
-                         "iterations, and restart steps come in runs; see gmres_outer_iters_per_step / ms_per_outer_iteration)")
+    ap.add_argument("--steps", type=int, default=100,
+                    help="timed time steps.  GMRES(28) needs a restart in some steps and not in others (17 - 28 or 40 - 50 outer "
+                         "iterations) and restart steps come in runs, so windows of 20 steps average anything from 20 to 36 outer "
+                         "iterations; 100 steps (12 s) are within ~10 %% of the 200- and 300-step means (profiles/r02_step_history.txt); "
+                         "see gmres_outer_iters_per_step / ms_per_outer_iteration")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--spinup", type=int, default=20,
                     help="untimed time steps that prepare the state before the warm-up: the reference starts from u0 = 0 with the inlet "

@@ -13,4 +13,6 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu --profile-steps 0 > $OUT/${TAG}_pmc_write.json 2> $OUT/${TAG}_pmc_write.err || exit 4
 cd $R && python3 tools/pmc_summary.py $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write > $OUT/${TAG}_pmc_fetch_write_per_kernel.json
 find $OUT/${TAG}_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/${TAG}_kernel_stats.csv
+# the raw traces (one row per launch) are tens of MB: gpurun merges at most 64 MiB back, keep the summaries only
+rm -rf $OUT/${TAG}_stats $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write
 echo profile set done
