@@ -722,7 +722,7 @@ static void mgs_chain(nsx_handle *h, Span sp, double *w, int dim, double *const 
 // No orthogonality of the basis is assumed: in exact arithmetic the coefficients ARE the chain's.
 constexpr int LS_C = 8;       // basis vectors per pass of the dot kernel
 constexpr int LS_VALS = 64;   // r_j at j, Gram row at 32 + i, |w|^2 before the sweep at 63
-constexpr int LS_BLOCKS = 256;
+constexpr int LS_BLOCKS = 2048;  // most workgroups of the dot kernel (partial sums per value)
 
 __global__ __launch_bounds__(256) void k_ls_dots(int n, int split, int gap, const double *__restrict__ w, MgsArgs V, int dim, double *__restrict__ partial) {
   __shared__ double sh[4][2 * LS_C + 1];
@@ -770,11 +770,13 @@ __global__ __launch_bounds__(256) void k_ls_dots(int n, int split, int gap, cons
   }
 }
 // vals[v] = fixed-order sum of the LS_BLOCKS partial sums of value v (one workgroup per value; unused values become 0)
-__global__ __launch_bounds__(256) void k_ls_finalize(int dim, const double *__restrict__ partial, double *__restrict__ vals) {
+__global__ __launch_bounds__(256) void k_ls_finalize(int dim, int nblk, const double *__restrict__ partial, double *__restrict__ vals) {
   __shared__ double sh[4];
   const int v = blockIdx.x;
   const bool used = v < dim || (v >= 32 && v < 32 + dim - 1) || v == 63;
-  const double a = used ? partial[(size_t)v * LS_BLOCKS + threadIdx.x] : 0.0;
+  double a = 0.0;
+  if (used)
+    for (int q = threadIdx.x; q < nblk; q += 256) a += partial[(size_t)v * LS_BLOCKS + q];
   const double t = gx_block_sum(a, sh);
   if (threadIdx.x == 0) vals[v] = t;
 }
@@ -824,8 +826,9 @@ static void mgs_lowsync(nsx_handle *h, Span sp, double *w, int dim, double *cons
   const int n = sp.n;
   {
     LaunchScope ls(h, "mgs_dots", 8.0 * n * (dim + 2.0 * cdiv(dim, LS_C)));
-    hipLaunchKernelGGL(k_ls_dots, dim3(LS_BLOCKS), dim3(256), 0, h->stream, n, sp.split, sp.gap, w, V, dim, h->ls_partial.p);
-    hipLaunchKernelGGL(k_ls_finalize, dim3(LS_VALS), dim3(256), 0, h->stream, dim, h->ls_partial.p, h->ls_vals.p);
+    const int nblk = std::max(1, std::min(LS_BLOCKS, cdiv(n, 1024)));  // depends on the local size only: the values are final before they travel
+    hipLaunchKernelGGL(k_ls_dots, dim3(nblk), dim3(256), 0, h->stream, n, sp.split, sp.gap, w, V, dim, h->ls_partial.p);
+    hipLaunchKernelGGL(k_ls_finalize, dim3(LS_VALS), dim3(256), 0, h->stream, dim, nblk, h->ls_partial.p, h->ls_vals.p);
   }
   comm_allreduce_partials(h, h->ls_vals.p, LS_VALS);  // collective 1: every r_j, the Gram row and |w|^2 before the sweep
   hipLaunchKernelGGL(k_ls_solve, dim3(1), dim3(64), 0, h->stream, dim, consider ? 1 : 0, h->ls_vals.p, gram, h->scal.p + slot0);
@@ -857,7 +860,9 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
     // distributed solve: two collectives per sweep (mgs_lowsync); NSX_MGS_LOWSYNC=0: one launch + all-reduce per link, as the
     // reference's MPI run does.  Without a Gram cache (or too many vectors for it) the chain as well.
     if (h->ls_mode < 0) h->ls_mode = !(getenv("NSX_MGS_LOWSYNC") && atoi(getenv("NSX_MGS_LOWSYNC")) == 0);  // read once per handle
-    if (h->comm && h->ls_mode && gram && dim <= 31) mgs_lowsync(h, sp, w, dim, vs, slot0, out, consider, gram);
+    // (one GPU, vector too long for the persistent sweep: the same two passes read the basis twice instead of four times)
+    const bool too_long = !h->comm && !h->mgs_disabled && per_thread > 20;
+    if ((h->comm || too_long) && h->ls_mode && gram && dim <= 31) mgs_lowsync(h, sp, w, dim, vs, slot0, out, consider, gram);
     else mgs_chain(h, sp, w, dim, vs, slot0, out, consider);
     return false;
   }
