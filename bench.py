@@ -130,12 +130,17 @@ def gpu_run(dofs, tables, steps, warmup, schur_blocks, device, profile_steps=5, 
             one_step(False)
         if barrier:
             barrier()
+        c0 = dev.comm_counters() if world > 1 else (0, 0)
         t0 = time.perf_counter()
         for _ in range(steps):
             stats.append(one_step(False))
         if barrier:
             barrier()
         elapsed = time.perf_counter() - t0
+        if world > 1 and stats:  # collectives this rank issued per timed step (nsx_comm_counters)
+            c1 = dev.comm_counters()
+            stats[0]["allreduces_per_step"] = (c1[0] - c0[0]) / float(steps)
+            stats[0]["ghost_exchanges_per_step"] = (c1[1] - c0[1]) / float(steps)
         state = (dev.gather_solution() if world > 1 else dev.solution_owned, t) if want_state else None
         # per-kernel HIP-event pass (separate from the throughput pass: event pairs perturb the launch stream)
         table, prof_stats = {}, []
@@ -356,7 +361,8 @@ def main():
         # ---- strong: the 1.09M-DoF mesh of the N = 1 line partitioned over the N GPUs
         el_s, stats_s, _, _, _, dofs_s = partitioned_run(BASE_LEVEL, args.ranks, args.schur_blocks, steps, warmup, 0)
         strong = {"time_steps_per_s_of_this_mesh": steps / el_s, "ms_per_step": 1e3 * el_s / steps, "n_dofs": dofs_s.n_dofs,
-                  "gmres_outer_iters_per_step": sum(s["outer_iterations"] for s in stats_s) / max(1, len(stats_s))}
+                  "gmres_outer_iters_per_step": sum(s["outer_iterations"] for s in stats_s) / max(1, len(stats_s)),
+                  "allreduces_per_step": stats_s[0].get("allreduces_per_step"), "ghost_exchanges_per_step": stats_s[0].get("ghost_exchanges_per_step")}
     if rank != 0:
         if world > 1:
             torch.distributed.destroy_process_group()
@@ -415,7 +421,8 @@ def main():
     }
     if strong:
         out["strong"] = strong
-        out["weak"] = {"value": weak_value, "time_steps_per_s_of_this_mesh": raw, "n_dofs": dofs.n_dofs}
+        out["weak"] = {"value": weak_value, "time_steps_per_s_of_this_mesh": raw, "n_dofs": dofs.n_dofs,
+                       "allreduces_per_step": stats[0].get("allreduces_per_step"), "ghost_exchanges_per_step": stats[0].get("ghost_exchanges_per_step")}
     layouts = committed_layouts()
     if layouts:
         out["preconditioner_layouts"] = layouts
