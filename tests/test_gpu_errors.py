@@ -117,7 +117,10 @@ def test_gram_schmidt_as_one_launch_equals_the_launch_per_link_chain(prob):
     linearity of the dot product: h_j = v_j.w_j0 - sum_i (v_i.v_j) h_i, identical in exact arithmetic whatever the basis, so the
     coefficients differ by the rounding of the sums only.  All must walk through the same history and end at the same vector."""
     res = []
-    cases = [{"NSX_MGS": "0"}, {"NSX_MGS_LINKS": "1"}, {"NSX_MGS_LINKS": "2"}, {"NSX_MGS_LINKS": "3"}, {"NSX_MGS_LINKS": "4"}, {"NSX_MGS_LINKS": "5"}]
+    # NSX_MGS_MAXWG=1: a resident grid of one workgroup cannot hold the vector (> 20 entries per thread), which is what a mesh of
+    # several million DoF does to the real grid: the sweep then runs as two passes (all dot products + the Gram row, then the updates)
+    cases = [{"NSX_MGS": "0"}, {"NSX_MGS_LINKS": "1"}, {"NSX_MGS_LINKS": "2"}, {"NSX_MGS_LINKS": "3"}, {"NSX_MGS_LINKS": "4"}, {"NSX_MGS_LINKS": "5"},
+             {"NSX_MGS_MAXWG": "1"}]
     for env in cases:
         os.environ.update(env)
         try:
