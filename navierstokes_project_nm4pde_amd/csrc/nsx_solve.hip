@@ -110,13 +110,13 @@ static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b,
   do {
     ahead = 0;
     if (x_is_zero) {
-      v_copy(h, n.n, p, b);  // inner solves only: plain vectors without a ghost gap
+      P(v, b);  // the residual b - A 0 is b itself: the preconditioner reads it where it is (p is only a temporary)
       x_is_zero = false;
     } else {
       A(p, x);
       v_sadd(h, n, p, -1., 1., b);
+      P(v, p);
     }
-    P(v, p);
     v_dot(h, n, v, v, S_NRM);
     double rho = std::sqrt(read_scalar(h, S_NRM));
     res.last = rho;
