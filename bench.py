@@ -225,11 +225,14 @@ def layout_table(device, out_path, steps=2):
     few large blocks run through the level-per-launch ILU path)."""
     import numpy as np  # noqa: F401
     rows = []
+    only = os.environ.get("NSX_LAYOUT_ONLY")  # e.g. "8:colour_all,1:colour_all": measure these rows only
     for ranks, schur in ((4096, 512), (8, 8), (1, 1)):
-        for ordering in ("colour", "first_touch"):
+        for ordering in ("colour", "first_touch") + (("colour_all",) if ranks <= 8 else ()):
+            if only and "%d:%s" % (ranks, ordering) not in only.split(","):
+                continue
             mesh, dofs, tables = build_problem(BASE_LEVEL, ranks, 1, ordering)
             t0 = time.perf_counter()
-            n = steps if ranks > 1 or ordering == "colour" else 1  # R = 1 first-touch: ~7000 dependency levels per sweep
+            n = steps if ranks > 1 or ordering != "first_touch" else 1  # R = 1 first-touch: ~7000 dependency levels per sweep
             elapsed, stats, _, _, _ = gpu_run(dofs, tables, n, 1, schur, device, profile_steps=0)
             row = {"ranks": ranks, "schur_blocks": schur, "ordering": ordering, "n_dofs": dofs.n_dofs, "steps": n,
                    "outer_per_step": sum(s["outer_iterations"] for s in stats) / n,
@@ -289,7 +292,7 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak", help="which figure becomes `value` for N > 1 (both are reported)")
     ap.add_argument("--ranks", type=int, default=4096, help="virtual MPI ranks = ILU(0) blocks of F")
     ap.add_argument("--schur-blocks", type=int, default=512, help="ILU(0) blocks of the Schur matrix")
-    ap.add_argument("--ordering", choices=("colour", "first_touch"), default="colour",
+    ap.add_argument("--ordering", choices=("colour", "first_touch", "colour_all"), default="colour",
                     help="velocity node order inside a virtual rank (include/nsx_host.h: nsxh_distribute_dofs_ordered)")
     ap.add_argument("--balance", choices=("cells", "owned"), default="cells",
                     help="what the partitioner equalises over the virtual ranks: cells (METIS-like) or owned P2 nodes = ILU block sizes")

@@ -76,10 +76,14 @@ nsxh_dofs *nsxh_distribute_dofs(const nsxh_mesh *);
  *   NSXH_ORDER_FIRST_TOUCH  cell by cell, vertices then lines (what nsxh_distribute_dofs does);
  *   NSXH_ORDER_COLOUR       velocity nodes sorted by a greedy colouring of the subdomain's P2 graph: the per-rank ILU(0)
  *                           gets a dependency graph as shallow as the number of colours.
- * Ownership, rank ranges and the pressure numbering are the same for both. */
-enum { NSXH_ORDER_FIRST_TOUCH = 0, NSXH_ORDER_COLOUR = 1 };
+ *   NSXH_ORDER_COLOUR_ALL   the same, and the pressure nodes sorted by a greedy colouring of the Schur complement's graph
+ *                           (B D^-1 B^T): for few large ranks (mpirun -n 1, one rank per GPU), where the ILU(0) of the Schur
+ *                           matrix is applied as sparse sweeps and its depth is what bounds them.
+ * Ownership and rank ranges are the same for all; the pressure numbering is the same for the first two. */
+enum { NSXH_ORDER_FIRST_TOUCH = 0, NSXH_ORDER_COLOUR = 1, NSXH_ORDER_COLOUR_ALL = 2 };
 nsxh_dofs *nsxh_distribute_dofs_ordered(const nsxh_mesh *, int ordering);
-int nsxh_n_colours(const nsxh_dofs *);       /* colours used by NSXH_ORDER_COLOUR, 0 otherwise */
+int nsxh_n_colours(const nsxh_dofs *);       /* colours of the velocity nodes (NSXH_ORDER_COLOUR, _ALL), 0 otherwise */
+int nsxh_n_colours_p(const nsxh_dofs *);     /* colours of the pressure nodes (NSXH_ORDER_COLOUR_ALL), 0 otherwise */
 void nsxh_dofs_free(nsxh_dofs *);
 
 int nsxh_dofs_per_cell(const nsxh_dofs *);   /* 15 (2D) / 34 (3D) */

@@ -40,6 +40,7 @@ def _lib():
         "nsxh_distribute_dofs": (vp, [vp]),
         "nsxh_distribute_dofs_ordered": (vp, [vp, C.c_int]),
         "nsxh_n_colours": (C.c_int, [vp]),
+        "nsxh_n_colours_p": (C.c_int, [vp]),
         "nsxh_write_vtu": (C.c_int, [vp, C.POINTER(C.c_double), C.c_char_p, C.c_char_p, C.c_uint]),
         "nsxh_pressure_difference": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "nsxh_dofs_free": (None, [vp]),
@@ -156,7 +157,7 @@ class Mesh:
 class DoFs:
     """Taylor-Hood P2/P1 DoF tables (FESystem local order; velocity block then pressure block)."""
 
-    ORDERINGS = {"first_touch": 0, "colour": 1}
+    ORDERINGS = {"first_touch": 0, "colour": 1, "colour_all": 2}
 
     def __init__(self, mesh, ordering="first_touch"):
         L = _lib()
@@ -166,6 +167,7 @@ class DoFs:
         if not h:
             raise ValueError("nsxh_distribute_dofs_ordered failed")
         self.n_colours = L.nsxh_n_colours(h)
+        self.n_colours_p = L.nsxh_n_colours_p(h)
         self.dim = mesh.dim
         nc = mesh.cells.shape[0]
         self.n_cells = nc

@@ -709,7 +709,7 @@ extern "C" nsxh_mesh *nsxh_mesh_read_msh(const char *path) { return read_msh_imp
 
 // ---------------------------------------------------------------- DoF handler
 struct nsxh_dofs {
-  int dim = 0, n_cells = 0, dpc = 0, n2 = 0, n1 = 0, n_sub = 1, n_colours = 0;
+  int dim = 0, n_cells = 0, dpc = 0, n2 = 0, n1 = 0, n_sub = 1, n_colours = 0, n_colours_p = 0;
   const nsxh_mesh *mesh = nullptr;
   std::vector<int32_t> cell_dofs;
   std::vector<int32_t> cell_nodes2, cell_nodes1;  // scalar connectivity
@@ -766,12 +766,68 @@ static void renumber_by_colour(nsxh_dofs *d, int np2) {
   for (auto &v : d->cell_nodes2) v = perm[v];
 }
 
+// NSXH_ORDER_COLOUR_ALL: the P1 (pressure) nodes of every subdomain as well, coloured on the graph of the Schur complement
+// B D^-1 B^T (two pressure nodes are adjacent when some P2 node shares a cell with each of them), because that is the matrix
+// whose per-rank ILU(0) is applied in every CG iteration.  With few large ranks (mpirun -n 1, one rank per GPU) the first-touch
+// pressure numbering gives that factorisation thousands of dependency levels; by colour it has as many as there are colours.
+static int renumber_pressure_by_colour(nsxh_dofs *d, int np2, int nv) {
+  const int nc = d->n_cells, n1 = (int)d->pnode_owner.size(), n2 = (int)d->node_owner.size();
+  auto incidence = [&](const std::vector<int32_t> &conn, int per_cell, int n, std::vector<int32_t> &ptr, std::vector<int32_t> &cells) {
+    ptr.assign((size_t)n + 1, 0);
+    for (size_t k = 0; k < conn.size(); ++k) ptr[conn[k] + 1]++;
+    for (int i = 0; i < n; ++i) ptr[i + 1] += ptr[i];
+    cells.resize(ptr[n]);
+    std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
+    for (int c = 0; c < nc; ++c)
+      for (int a = 0; a < per_cell; ++a) cells[fill[conn[(size_t)c * per_cell + a]]++] = c;
+  };
+  std::vector<int32_t> pptr, pcell, nptr, ncell;
+  incidence(d->cell_nodes1, nv, n1, pptr, pcell);
+  incidence(d->cell_nodes2, np2, n2, nptr, ncell);
+  std::vector<int32_t> colour(n1, -1), perm(n1), seen2(n2, -1), seenc(nc, -1);
+  std::vector<uint8_t> used;
+  int max_col = 0;
+  for (int i = 0; i < n1; ++i) {
+    used.assign(max_col + 2, 0);
+    for (int k = pptr[i]; k < pptr[i + 1]; ++k)
+      for (int a = 0; a < np2; ++a) {
+        const int m2 = d->cell_nodes2[(size_t)pcell[k] * np2 + a];
+        if (seen2[m2] == i) continue;
+        seen2[m2] = i;
+        for (int q = nptr[m2]; q < nptr[m2 + 1]; ++q) {
+          const int c2 = ncell[q];
+          if (seenc[c2] == i) continue;
+          seenc[c2] = i;
+          for (int b = 0; b < nv; ++b) {
+            const int j = d->cell_nodes1[(size_t)c2 * nv + b];
+            if (j != i && d->pnode_owner[j] == d->pnode_owner[i] && colour[j] >= 0) used[colour[j]] = 1;
+          }
+        }
+      }
+    int c = 0;
+    while (used[c]) ++c;
+    colour[i] = c;
+    if (c + 1 > max_col) max_col = c + 1;
+  }
+  for (int s = 0; s < d->n_sub; ++s) {
+    const int r0 = d->owned_p_ptr[s], r1 = d->owned_p_ptr[s + 1];
+    std::vector<int32_t> idx(r1 - r0);
+    std::iota(idx.begin(), idx.end(), r0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) { return colour[a] < colour[b]; });
+    for (int k = 0; k < r1 - r0; ++k) perm[idx[k]] = r0 + k;
+  }
+  for (auto &v : d->vertex_pnode)
+    if (v >= 0) v = perm[v];
+  for (auto &v : d->cell_nodes1) v = perm[v];
+  return max_col;
+}
+
 extern "C" {
 
 nsxh_dofs *nsxh_distribute_dofs(const nsxh_mesh *m) { return nsxh_distribute_dofs_ordered(m, NSXH_ORDER_FIRST_TOUCH); }
 
 nsxh_dofs *nsxh_distribute_dofs_ordered(const nsxh_mesh *m, int ordering) {
-  if (!m || (ordering != NSXH_ORDER_FIRST_TOUCH && ordering != NSXH_ORDER_COLOUR)) return nullptr;
+  if (!m || (ordering != NSXH_ORDER_FIRST_TOUCH && ordering != NSXH_ORDER_COLOUR && ordering != NSXH_ORDER_COLOUR_ALL)) return nullptr;
   auto *d = new nsxh_dofs;
   const int dim = m->dim, nv = dim + 1, nl = dim == 2 ? 3 : 6, nc = m->n_cells();
   d->dim = dim;
@@ -824,7 +880,8 @@ nsxh_dofs *nsxh_distribute_dofs_ordered(const nsxh_mesh *m, int ordering) {
   }
   d->n2 = next2;
   d->n1 = next1;
-  if (ordering == NSXH_ORDER_COLOUR) renumber_by_colour(d, np2);
+  if (ordering == NSXH_ORDER_COLOUR || ordering == NSXH_ORDER_COLOUR_ALL) renumber_by_colour(d, np2);
+  if (ordering == NSXH_ORDER_COLOUR_ALL) d->n_colours_p = renumber_pressure_by_colour(d, np2, nv);
   const int32_t n_u = dim * next2;
   d->cell_dofs.resize((size_t)nc * d->dpc);
   d->cell_coords.resize((size_t)nc * nv * dim);
@@ -871,6 +928,7 @@ const int32_t *nsxh_owned_u_ptr(const nsxh_dofs *d) { return d->owned_u_ptr.data
 const int32_t *nsxh_owned_p_ptr(const nsxh_dofs *d) { return d->owned_p_ptr.data(); }
 int nsxh_n_subdomains(const nsxh_dofs *d) { return d->n_sub; }
 int nsxh_n_colours(const nsxh_dofs *d) { return d->n_colours; }
+int nsxh_n_colours_p(const nsxh_dofs *d) { return d->n_colours_p; }
 
 int nsxh_boundary_dofs(nsxh_dofs *d, int boundary_id, const int32_t **dofs) {
   auto it = d->bdofs.find(boundary_id);

@@ -256,3 +256,38 @@ def test_partition_owned_balances_the_ilu_blocks():
     assert sizes["owned"].max() < 1.2 * sizes["owned"].mean()
     assert sizes["cells"].max() > 1.4 * sizes["cells"].mean()
     assert sizes["owned"].max() < sizes["cells"].max()
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_colour_all_also_orders_the_pressure_nodes_by_colour_of_the_schur_graph(dim):
+    """NSXH_ORDER_COLOUR_ALL: velocity nodes as NSXH_ORDER_COLOUR, pressure nodes of every rank sorted by a colouring of
+    the graph of B D^-1 B^T (two P1 nodes adjacent when some P2 node shares a cell with each).  Rank-local permutation;
+    the ILU(0) of a rank's Schur block is then at most n_colours_p levels deep."""
+    import scipy.sparse as sp
+    m = Mesh.cylinder(dim, 1).partition(1, 3)
+    d1, d2 = DoFs(m, "colour"), DoFs(m, "colour_all")
+    assert d1.n_colours_p == 0 and d2.n_colours_p >= dim + 1 and d2.n_colours == d1.n_colours
+    nv, nl = dim + 1, 3 if dim == 2 else 6
+    ucols = [(dim + 1) * v + k for v in range(nv) for k in range(dim)] + [nv * (dim + 1) + dim * l + k for l in range(nl) for k in range(dim)]
+    pc = [(dim + 1) * v + dim for v in range(nv)]
+    assert (d2.cell_dofs[:, ucols] == d1.cell_dofs[:, ucols]).all()               # velocity numbering as "colour"
+    p1, p2 = d1.cell_dofs[:, pc] - d1.n_u, d2.cell_dofs[:, pc] - d2.n_u
+    perm = np.full(d1.n_p, -1)
+    perm[p1.ravel()] = p2.ravel()
+    assert sorted(perm.tolist()) == list(range(d1.n_p))
+    assert (d2.pnode_owner == d1.pnode_owner).all() and (d2.pnode_owner[perm] == d1.pnode_owner).all()
+    assert (d2.owned_p_ptr == d1.owned_p_ptr).all() and (d2.owned_u_ptr == d1.owned_u_ptr).all()
+    assert np.allclose(d2.support_points[d2.cell_dofs], d1.support_points[d1.cell_dofs])
+    # pattern of B (P1 x P2 nodes) from the cells, S = B B^T, depth of the in-rank lower triangle
+    cols2 = [(dim + 1) * v for v in range(nv)] + [nv * (dim + 1) + dim * l for l in range(nl)]
+    n2 = d2.cell_dofs[:, cols2] // dim
+    r = np.repeat(p2, n2.shape[1], axis=1).ravel()
+    c = np.tile(n2, (1, p2.shape[1])).ravel()
+    B = sp.csr_matrix((np.ones(len(r)), (r, c)), shape=(d2.n_p, d2.n_nodes_p2))
+    S = (B @ B.T).tocsr()
+    depth = np.zeros(d2.n_p, dtype=int)
+    for i in range(d2.n_p):
+        nb = S.indices[S.indptr[i]:S.indptr[i + 1]]
+        nb = nb[(nb < i) & (d2.pnode_owner[nb] == d2.pnode_owner[i])]
+        depth[i] = depth[nb].max() + 1 if len(nb) else 0
+    assert depth.max() + 1 <= d2.n_colours_p
