@@ -36,7 +36,8 @@ def _scalar_factor_of_oracle(p, ora, n_lu):
     return ora.ilu_F()[sel]
 
 
-@pytest.mark.parametrize("case", [("cylinder", 3, 1, 1, "first_touch"), ("cylinder", 3, 1, 3, "colour"), ("cylinder", 2, 2, 2, "first_touch")],
+@pytest.mark.parametrize("case", [("cylinder", 3, 1, 1, "first_touch"), ("cylinder", 3, 1, 3, "colour"), ("cylinder", 2, 2, 2, "first_touch"),
+                                  ("cylinder", 3, 1, 2, "colour_all")],   # pressure nodes by colour of the Schur graph as well
                          ids=lambda c: "%s%dd-l%d-r%d-%s" % c)
 def test_levelled_factor_solve_and_step_match_oracle(forced_levelled, case):
     import oracle
