@@ -7,7 +7,8 @@ One "step" = NavierStokes::assemble_time_step + apply_boundary_values + solve_ti
 dt = 2e-4, nu = 1e-3, u_m = 9 (reference defaults).  Inputs are resident in HBM when the timed
 region starts; VTU output and forces are excluded.  The run starts from u0 = 0 with the inlet switched on
 impulsively, as the reference does; the first step (full assembly) and --spinup further steps (default 20, SURVEY 8d:
-"timing uses steps after a fixed warm-up") prepare the state, then come W warm-up steps and exactly K timed steps.
+"timing uses steps after a fixed warm-up") prepare the state, then come W warm-up steps and exactly K timed steps (default
+K = 100 on one GPU; under a launcher K = 30 behind 10 preparation steps, because every invocation then makes two partitioned runs).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--level L] [--ranks R] [--schur-blocks S]
 
@@ -279,13 +280,14 @@ def summarise_kernels(table, prof_stats):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100,
+    ap.add_argument("--steps", type=int, default=None,
                     help="timed time steps.  GMRES(28) needs a restart in some steps and not in others (17 - 28 or 40 - 50 outer "
                          "iterations) and restart steps come in runs, so windows of 20 steps average anything from 20 to 36 outer "
                          "iterations; 100 steps (12 s) are within ~10 %% of the 200- and 300-step means (profiles/r02_step_history.txt); "
-                         "see gmres_outer_iters_per_step / ms_per_outer_iteration")
+                         "see gmres_outer_iters_per_step / ms_per_outer_iteration.  Default: 100 on one GPU, 30 under a launcher "
+                         "(two partitioned runs per invocation, every step latency bound: the job must stay within minutes)")
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--spinup", type=int, default=20,
+    ap.add_argument("--spinup", type=int, default=None,
                     help="untimed time steps that prepare the state before the warm-up: the reference starts from u0 = 0 with the inlet "
                          "switched on impulsively, and SURVEY 8d times steps after a fixed warm-up of ~20 steps past that transient")
     ap.add_argument("--level", type=int, default=None, help="mesh level (default: 7 ~ 1.09M DoF per GPU)")
@@ -303,6 +305,10 @@ def main():
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.steps is None:
+        args.steps = 100 if max(world, args.gpus) == 1 else 30
+    if args.spinup is None:
+        args.spinup = 20 if max(world, args.gpus) == 1 else 10
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # not under a launcher: start one process per GPU as a CHILD (nothing here has touched the GPU yet) and relay its line
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
