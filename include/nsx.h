@@ -69,6 +69,8 @@ typedef struct {
   double t_prec;           /* seconds, preconditioner initialize (reference NavierStokes3D.cpp:558-572, time_prec) */
   double t_solve;          /* seconds, outer solve               (reference NavierStokes3D.cpp:573-577, time_solve) */
   int status;              /* 0 ok, 1 outer GMRES not converged, 2 an inner solve not converged */
+  int persistent_fallbacks; /* persistent kernels (Gram-Schmidt sweep, Schur CG) that timed out on this handle SO FAR because their grid was
+                            * not co-resident; the handle then stays on the launch-per-operation path.  0 in a healthy run. */
 } nsx_solve_stats;
 
 /* ---- life cycle ---- */
@@ -174,6 +176,12 @@ int nsx_profile_enable(nsx_handle *h, int on);
 int nsx_profile_reset(nsx_handle *h);
 int nsx_profile_count(nsx_handle *h);
 int nsx_profile_get(nsx_handle *h, int i, const char **name, int64_t *launches, double *total_ms, double *bytes_per_launch);
+
+/* State of the two persistent (single-launch, grid-wide-exchange) kernels of this handle, for tests and bench.py:
+ * state[0] / state[1] = 1 while the Gram-Schmidt sweep / the Schur-complement CG run as ONE launch (0: never used yet, switched
+ * off, or fallen back), state[2] = time-outs so far (= nsx_solve_stats::persistent_fallbacks), state[3] = mailbox words that are
+ * not empty in the region the next launch would use (0 on a healthy handle and after a recovered time-out). */
+int nsx_persistent_state(nsx_handle *h, int state[4]);
 
 /* ---- multi-GPU (one process per GPU, RCCL over xGMI) ---- */
 /* Replaces the MPI communicator inside Epetra (reference NavierStokes3D.hpp:93-94,102): MPI_Allreduce behind every

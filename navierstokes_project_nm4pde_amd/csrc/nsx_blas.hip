@@ -255,7 +255,7 @@ template <int E>
 __global__ __launch_bounds__(256) void k_mgs(int n, int split, int gap, double *__restrict__ w, MgsArgs V, int dim,
                                              unsigned long long *box, unsigned long long *box_next, int reset_wg, int reset_steps,
                                              double *__restrict__ scal_out, int *err_host, unsigned long long *tail, int normalize, int consider,
-                                             double *pub_vals, unsigned long long *pub_flag, unsigned long long seq) {
+                                             double *pub_vals, unsigned long long *pub_flag, unsigned long long seq, int drop_wg) {
   __shared__ double sh[2][4];  // two buffers: a wave may start the next sum while a slower one still reads this one
   __shared__ unsigned long long bc;
   __shared__ int s_err;  // raised by any thread whose wait timed out; read after the next barrier
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void k_mgs(int n, int split, int gap, double *
     for (int k = 0; k < E; ++k) acc += wv[k] * ((!pre && s < dim) ? vc[k] : wv[k]);
     const double part = gx_block_sum(acc, sh[0]);
     unsigned long long *row = box + (size_t)ri * MGS_MAX_WG;
-    if (threadIdx.x == 0) gx_post(row + wg, part);
+    if (threadIdx.x == 0 && wg != drop_wg) gx_post(row + wg, part);  // drop_wg >= 0: fault injection (NSX_GX_DROP_WG), a workgroup that never arrives
     if (wg == 0) {
       double a = 0.0;
       for (int q = threadIdx.x; q < nwg; q += 256) a += gx_wait_value(row + q, &lerr);
@@ -400,7 +400,7 @@ template <int E, int M, bool PF>
 __global__ __launch_bounds__(256) void k_mgs_blk(int n, int split, int gap, double *__restrict__ w, MgsArgs V, int dim, unsigned long long *box,
                                                  unsigned long long *box_next, int reset_words, double *__restrict__ scal_out, int *err_host,
                                                  unsigned long long *tail, int normalize, int consider, double *pub_vals,
-                                                 unsigned long long *pub_flag, unsigned long long seq) {
+                                                 unsigned long long *pub_flag, unsigned long long seq, int drop_wg) {
   constexpr int NP = M * (M - 1) / 2, NV = M + NP + 1;  // r_0..r_{M-1}, pairs (i < j) at M + j (j - 1) / 2 + i, |w|^2 before the sweep
   __shared__ double sh[4][NV];
   __shared__ double bc[M + 1];
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256) void k_mgs_blk(int n, int split, int gap, doub
     __syncthreads();
     MGS_STAMP();  // local sums done (the block's loads have arrived)
     unsigned long long *xbox = box + (size_t)x * NV * nwg;
-    if (threadIdx.x < NV && (used >> threadIdx.x & 1u)) {
+    if (threadIdx.x < NV && (used >> threadIdx.x & 1u) && wg != drop_wg) {  // drop_wg: fault injection, see k_mgs
       const int v = threadIdx.x;
       gx_post(xbox + (size_t)v * nwg + wg, (sh[0][v] + sh[1][v]) + (sh[2][v] + sh[3][v]));
     }
@@ -667,7 +667,6 @@ static void mgs_setup(nsx_handle *h) {
     if (getenv("NSX_DEBUG")) fprintf(stderr, "[nsx] mgs sweep (%d links per exchange, %d entries per thread): %d CUs x %d resident workgroups\n", h->mgs_links, es[k], cus, per_cu);
   }
   h->mgs_max_wg = h->mgs_max_wg_e[1];
-  h->mgs_coop = getenv("NSX_MGS_COOP") && atoi(getenv("NSX_MGS_COOP")) != 0;
 }
 
 void wait_published(nsx_handle *h, unsigned long long seq) {
@@ -697,9 +696,10 @@ static unsigned int mgs_recover(nsx_handle *h, unsigned long long failed_seq) {
   h->mgs_used_wg[0] = h->mgs_used_wg[1] = h->mgs_used_steps[0] = h->mgs_used_steps[1] = 0;
   h->mgs_max_wg = h->mgs_max_wg_e[0] = h->mgs_max_wg_e[1] = h->mgs_max_wg_e[2] = 0;
   h->mgs_disabled = true;
+  h->n_persistent_fallbacks++;
   unsigned int committed = 0;
   for (unsigned long long v : tail) committed += v == failed_seq;
-  if (getenv("NSX_DEBUG")) fprintf(stderr, "[nsx] Gram-Schmidt sweep timed out (grid not co-resident): using one launch per link from now on\n");
+  fprintf(stderr, "[nsx] warning: the persistent Gram-Schmidt sweep timed out (grid not co-resident): this handle uses one launch per link from now on\n");
   return committed;
 }
 
@@ -881,25 +881,24 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
     int *err = (int *)(h->pub_dev + N_SLOTS + 2);  // mapped host word
     unsigned long long *tail = h->mgs_box.p + 2 * region;
     int reset_wg = h->mgs_used_wg[1 - h->mgs_parity], reset_steps = h->mgs_used_steps[1 - h->mgs_parity];
+    int drop_wg = h->gx_drop_wg;
     // Co-residency: the grid never exceeds what the device holds at once (mgs_setup), the stream is in-order and normally nothing
-    // else runs on the device, so a plain launch places every workgroup at once.  hipLaunchCooperativeKernel (NSX_MGS_COOP=1) adds
-    // a launch-time size check and ~20 us of cross-queue synchronisation per launch, but no residency guarantee beyond that
-    // (/opt/skills/guides/MI355X_MICROARCH.md, "Residency and cooperative launch").  What makes the sweep safe is the bounded wait:
-    // should a workgroup be missing (another stream or process holds compute units), the kernel ends without writing w and the
-    // sweep is redone by the launch-per-link chain below.
+    // else runs on the device, so a plain launch places every workgroup at once.  (hipLaunchCooperativeKernel was an option until
+    // round 3: it adds a launch-time size check and ~20 us of cross-queue synchronisation per launch but no residency guarantee
+    // beyond that — /opt/skills/guides/MI355X_MICROARCH.md, "Residency and cooperative launch" — and was removed.)  What makes the
+    // sweep safe is the bounded wait: should a workgroup be missing (another stream or process holds compute units), the kernel
+    // ends without writing w and the sweep is redone by the launch-per-link chain below.
     const void *fn = mgs_fn(M, e_inst);
     if (M == 1) {
-      void *args[] = {&n_, &split, &gap, &w, &V, &dim_, &box, &box_next, &reset_wg, &reset_steps, &sout, &err, &tail, &norm_, &consider_, &pub_vals, &pub_flag, &seq_};
-      if (h->mgs_coop) HIP_CHECK(hipLaunchCooperativeKernel(fn, dim3(nwg), dim3(256), args, 0, h->stream));
-      else HIP_CHECK(hipLaunchKernel(fn, dim3(nwg), dim3(256), args, 0, h->stream));
+      void *args[] = {&n_, &split, &gap, &w, &V, &dim_, &box, &box_next, &reset_wg, &reset_steps, &sout, &err, &tail, &norm_, &consider_, &pub_vals, &pub_flag, &seq_, &drop_wg};
+      HIP_CHECK(hipLaunchKernel(fn, dim3(nwg), dim3(256), args, 0, h->stream));
       h->mgs_used_wg[h->mgs_parity] = nwg;
       h->mgs_used_steps[h->mgs_parity] = dim + 2;
     } else {
       // k_mgs_blk: the region is a flat array of (exchanges x values x workgroups) words; "steps" counts words, "wg" is 1
       int reset_words = reset_wg * reset_steps;
-      void *args[] = {&n_, &split, &gap, &w, &V, &dim_, &box, &box_next, &reset_words, &sout, &err, &tail, &norm_, &consider_, &pub_vals, &pub_flag, &seq_};
-      if (h->mgs_coop) HIP_CHECK(hipLaunchCooperativeKernel(fn, dim3(nwg), dim3(256), args, 0, h->stream));
-      else HIP_CHECK(hipLaunchKernel(fn, dim3(nwg), dim3(256), args, 0, h->stream));
+      void *args[] = {&n_, &split, &gap, &w, &V, &dim_, &box, &box_next, &reset_words, &sout, &err, &tail, &norm_, &consider_, &pub_vals, &pub_flag, &seq_, &drop_wg};
+      HIP_CHECK(hipLaunchKernel(fn, dim3(nwg), dim3(256), args, 0, h->stream));
       const int nv = M + M * (M - 1) / 2 + 1;
       h->mgs_used_wg[h->mgs_parity] = 1;
       h->mgs_used_steps[h->mgs_parity] = (cdiv(dim, M) + 1) * nv * nwg;
@@ -1063,4 +1062,33 @@ void write_scalar(nsx_handle *h, int slot, double v) {
   HIP_CHECK(hipStreamSynchronize(h->stream));
 }
 
+int cg_dirty_words(nsx_handle *h);
+// diagnostics (nsx_persistent_state): words of the region the next sweep would use that are not empty.  A healthy handle keeps
+// that region empty (every launch clears the other region for its successor); after a time-out mgs_recover clears both.
+static int mgs_dirty_words(nsx_handle *h) {
+  if (!h->mgs_box.p) return 0;
+  const size_t region = std::max(MGS_REGION, MGS_BLK_REGION);
+  std::vector<unsigned long long> w(region);
+  HIP_CHECK(hipStreamSynchronize(h->stream));
+  HIP_CHECK(hipMemcpy(w.data(), h->mgs_box.p + (size_t)h->mgs_parity * region, region * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  int dirty = 0;
+  for (unsigned long long v : w) dirty += v != GX_EMPTY;
+  return dirty;
+}
+
 }  // namespace nsx
+
+extern "C" int nsx_persistent_state(nsx_handle *h, int state[4]) {
+  if (!h || !state) return NSX_ERR_ARG;
+  try {
+    HIP_CHECK(hipSetDevice(h->prm.device));
+    state[0] = h->mgs_box.p != nullptr && !h->mgs_disabled && h->mgs_max_wg > 0;
+    state[1] = h->cg_box.p != nullptr && !h->cg_disabled && h->cg_max_wg > 0;
+    state[2] = h->n_persistent_fallbacks;
+    state[3] = nsx::mgs_dirty_words(h) + nsx::cg_dirty_words(h);
+  } catch (const nsx::Error &e) {
+    h->err = e.msg;
+    return e.code;
+  }
+  return NSX_OK;
+}

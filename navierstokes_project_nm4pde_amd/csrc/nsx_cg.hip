@@ -63,7 +63,7 @@ __device__ __forceinline__ double cg_sum8(const double *w) {  // the per-wave su
 }
 
 template <int NV>
-__device__ __forceinline__ void cg_post(const double (&part)[NV], unsigned long long *box, int e, int nwg, double (*sh)[CG_NV * 8], int *s_err) {
+__device__ __forceinline__ void cg_post(const double (&part)[NV], unsigned long long *box, int e, int nwg, double (*sh)[CG_NV * 8], int *s_err, bool drop = false) {
   const int wg = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
   const CgBox bx = cg_box_of(box, e);
   double *buf = sh[2 * (e & 1)], *buf0 = sh[2 * (e & 1) + 1];
@@ -79,7 +79,8 @@ __device__ __forceinline__ void cg_post(const double (&part)[NV], unsigned long 
   __syncthreads();
   if (tid == 0) {
 #pragma unroll
-    for (int v = 0; v < NV; ++v) gx_post(bx.row + (size_t)v * CG_MAX_WG + wg, cg_sum8(buf + v * 8));
+    for (int v = 0; v < NV; ++v)
+      if (!drop) gx_post(bx.row + (size_t)v * CG_MAX_WG + wg, cg_sum8(buf + v * 8));  // drop: fault injection (NSX_GX_DROP_WG)
 #pragma unroll
     for (int v = 0; v < CG_NV; ++v) gx_clear(bx.row2 + (size_t)v * CG_MAX_WG + wg);
   }
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(CG_THREADS) void k_cg_schur(const int32_t *__restri
                                                   const int32_t *__restrict__ sinfo, const int64_t *__restrict__ dn_off,
                                                   const double *__restrict__ P, const double *__restrict__ b, double *x, double *D0, double *D1,
                                                   double *H, double rtol, int maxiter, unsigned long long *box, unsigned long long *box_other,
-                                                  double *pub_vals, unsigned long long *pub_flag, unsigned long long seq, int *err_dev) {
+                                                  double *pub_vals, unsigned long long *pub_flag, unsigned long long seq, int *err_dev, int drop_wg) {
   __shared__ double gs[CG_MAXB], hs[CG_MAXB], ds[CG_MAXB], hvs[CG_MAXB], xs[CG_MAXB], xst[CG_MAX_UCOLS];
   __shared__ double sh[4][CG_NV * 8], bc[CG_NV];
   __shared__ int s_err;
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(CG_THREADS) void k_cg_schur(const int32_t *__restri
   double tot3[3];
   {
     const double part[3] = {own ? gs[tid] * gs[tid] : 0.0, own ? bi * bi : 0.0, own ? gs[tid] * hs[tid] : 0.0};
-    cg_post<3>(part, box, e, nwg, sh, &s_err);
+    cg_post<3>(part, box, e, nwg, sh, &s_err, wg == drop_wg);
     cg_spmv_prefetch(s0, s1, sval, slidx, ht, va, la);  // the operator values of the first iteration ride on the exchange
     if (!cg_collect<3>(tot3, box, e++, bc, &s_err)) {
       if (tid == 0) __hip_atomic_store(err_dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -478,7 +479,7 @@ bool cg_schur_persistent(nsx_handle *h, double *x, const double *b, double rtol,
     pe = ls.e;
     hipLaunchKernelGGL(k_cg_schur, dim3(s.n_blocks), dim3(CG_THREADS), 0, h->stream, s.block_ptr.p, pl.u_ptr.p, pl.u_cols.p, pl.s_ptr.p, pl.s_val.p,
                        pl.s_lidx.p, pl.s_info.p, s.dn_off.p, s.dn_P.p, b, x, D0, D1, H, rtol, maxiter, box, box_other, pub_vals, pub_flag, seq,
-                       err_dev);
+                       err_dev, h->gx_drop_wg);
   }
   h->cg_parity ^= 1;
   wait_published(h, seq);
@@ -491,7 +492,8 @@ bool cg_schur_persistent(nsx_handle *h, double *x, const double *b, double rtol,
     HIP_CHECK(hipMemsetAsync(h->cg_box.p + 2 * CG_REGION, 0, 2 * sizeof(unsigned long long), h->stream));
     h->cg_max_wg = 0;
     h->cg_disabled = true;
-    if (getenv("NSX_DEBUG")) fprintf(stderr, "[nsx] persistent Schur CG timed out: falling back to one launch per operation\n");
+    h->n_persistent_fallbacks++;
+    fprintf(stderr, "[nsx] warning: the persistent Schur CG timed out (grid not co-resident): this handle uses one launch per operation from now on\n");
     return false;
   }
   *steps = (int)h->pub_host[S_CGP];
@@ -500,6 +502,19 @@ bool cg_schur_persistent(nsx_handle *h, double *x, const double *b, double rtol,
   // algorithmic bytes: per iteration the matrix (12 B / entry) and the block inverses once, plus the vectors
   if (pe) pe->bytes += (double)(*steps + 1) * (10.0 * h->gS.nnz() + 8.0 * (double)s.dn_entries + 48.0 * n);
   return true;
+}
+
+// diagnostics (nsx_persistent_state): mailbox words of both regions that are not empty while nothing is in flight
+int cg_dirty_words(nsx_handle *h) {
+  if (!h->cg_box.p) return 0;
+  std::vector<unsigned long long> w(2 * CG_REGION);
+  HIP_CHECK(hipStreamSynchronize(h->stream));
+  HIP_CHECK(hipMemcpy(w.data(), h->cg_box.p, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  // the region the next launch will use must be all empty; the other one holds the last solve's sums (its successor clears it)
+  const size_t base = (size_t)h->cg_parity * CG_REGION;
+  int dirty = 0;
+  for (size_t q = 0; q < CG_REGION; ++q) dirty += w[base + q] != GX_EMPTY;
+  return dirty;
 }
 
 }  // namespace nsx

@@ -120,6 +120,12 @@ struct IluSchedule {
   int max_levels = 0;
   // packed solve stream (one wave per group of blocks): slabs of 64 slots {value, meta}; meta = col | last_of_step<<15 | (dst_row+1)<<16 | row_uses_a_pair_of_groups<<31
   int lanes_per_row = 8;
+  bool stream = false;          // true: lane-owner stream (host/ilu_stream.hpp, k_ilu_solve_lanes); false: the round-2 lane-group stream above
+  int stream_ncomp = 0;         // the stream holds LDS byte addresses: it is built for one number of interleaved right-hand sides
+  int stream_epl = 1;           // entries of its row a lane takes per tick (NSX_ILU_EPT)
+  DevBuf<int32_t> pk_row_ptr, pk_rows;  // lane-owner stream: the rows of every wave in LDS order ([n_waves+1] offsets, global row ids)
+  DevBuf<int32_t> pk_dinv_slot;         // lane-owner stream: position of row i's inverse pivot in pk_dinv (wave order)
+  int64_t in_block_nnz = 0;     // in-block entries of the factor, diagonal included: what one application has to read (algorithmic bytes)
   int64_t n_slabs = 0;
   int blocks_per_wave = 1, n_waves = 0, max_wave_rows = 0;
   bool packed_ok = false;
@@ -243,7 +249,7 @@ struct nsx_handle {
   // ---- preconditioner vectors
   nsx::DevBuf<double> diag_D, diag_D_inv, neg_diag_D_inv, lump_M, schur_w;
   nsx::DevBuf<double> schur_w_prev;        // weights the current Schur product / its factors were computed from
-  bool schur_valid = false;
+  bool schur_valid = false, schur_pending = false;  // pending: rebuilt in this initialisation, not yet confirmed (prec_confirm)
   int schur_type = -1;
   // ---- Krylov workspace
   std::vector<nsx::DevBuf<double> *> pool;  // temporary vectors handed out by size
@@ -263,7 +269,9 @@ struct nsx_handle {
   int mgs_parity = 0, mgs_max_wg = 0;  // mgs_max_wg = 0: the launch-per-link chain is used
   int mgs_max_wg_e[3] = {0, 0, 0};     // resident-grid limit of the 8 / 10 / 20 entries-per-thread instantiations
   int mgs_links = 2;                   // links of the add_and_dot chain per grid-wide exchange (NSX_MGS_LINKS; 1 = k_mgs)
-  bool mgs_coop = false, mgs_disabled = false;
+  bool mgs_disabled = false;
+  int gx_drop_wg = -1;                 // NSX_GX_DROP_WG (fault injection, tests): this workgroup of a persistent grid never posts its sums
+  int n_persistent_fallbacks = 0;      // persistent kernels that timed out on this handle (nsx_solve_stats::persistent_fallbacks)
   // distributed sweep with two collectives (mgs_lowsync): partial sums / all-reduced values / one 32 x 32 Gram matrix per GMRES nesting level
   nsx::DevBuf<double> ls_partial, ls_vals, ls_gram;
   int gmres_depth = 0, ls_mode = -1;
@@ -316,7 +324,7 @@ inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // ---- kernels / steps implemented across the .hip files
 void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> &block_ptr, IluSchedule &s, int lanes_per_row, int blocks_per_wave,
-                        bool allow_dense = false, bool allow_wide_rows = false);
+                        bool allow_dense = false, bool allow_wide_rows = false, int ncomp = 1);
 void build_schur_graph(nsx_handle *h);
 void ensure_schedules(nsx_handle *h);  // (re)build the ILU schedules if the rank / Schur block tables changed
 
@@ -407,6 +415,7 @@ void write_scalar(nsx_handle *h, int slot, double v);
 
 // solver (nsx_solve.hip)
 void prec_initialize(nsx_handle *h, int type);
+void prec_confirm(nsx_handle *h);  // after the synchronisation behind prec_initialize: ilu_check + the Schur values become reusable
 void prec_vmult(nsx_handle *h, int type, double inner_rtol, int inner_maxiter, double *dst, const double *src,
                 nsx_solve_stats *st);
 void solve_time_step(nsx_handle *h, int type, double tol, double inner_rtol, int maxiter, int inner_maxiter,

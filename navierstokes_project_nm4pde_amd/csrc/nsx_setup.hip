@@ -7,6 +7,7 @@
 #include <numeric>
 
 #include "nsx_internal.hpp"
+#include "../host/ilu_stream.hpp"
 
 using namespace nsx;
 
@@ -66,7 +67,7 @@ static void build_gather(nsx_handle *h, const Csr &g, int n_cells, int per_r, co
 }
 
 void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> &bptr, IluSchedule &s, int lanes_per_row, int blocks_per_wave,
-                        bool allow_dense, bool allow_wide_rows) {
+                        bool allow_dense, bool allow_wide_rows, int ncomp) {
   const int nb = (int)bptr.size() - 1;
   s.n_blocks = nb;
   s.block_ptr_h = bptr;
@@ -118,6 +119,10 @@ void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> 
       s.max_levels = std::max(s.max_levels, nl);
     }
   }
+  s.in_block_nnz = 0;
+  for (int b = 0; b < nb; ++b)
+    for (int i = bptr[b]; i < bptr[b + 1]; ++i)
+      for (int q = g.rowptr[i]; q < g.rowptr[i + 1]; ++q) s.in_block_nnz += g.colind[q] >= bptr[b] && g.colind[q] < bptr[b + 1];
   // ---- blocks beyond what one wave (packed stream) or one workgroup can hold: merged level lists, one launch per level
   const int levelled_min = getenv("NSX_LEVELLED_MIN") ? atoi(getenv("NSX_LEVELLED_MIN")) : 4096;
   s.levelled = s.max_rows > levelled_min;
@@ -167,6 +172,41 @@ void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> 
   // whose dependencies were finished in earlier steps, longest remaining dependency chain first, LW lanes per row.
   // A step occupies K slabs of 64 slots, slot (k, lane) = entry lane%LW + k*LW of row-group lane/LW.  Columns and
   // destinations are row indices into the wave's LDS copy of x (its blocks back to back).
+  // Default: the lane-owner stream (host/ilu_stream.hpp, k_ilu_solve_lanes).  NSX_ILU_STREAM=0: the round-2 lane-group stream
+  // (LW lanes per row, DPP reductions per step: k_ilu_solve_packed).
+  s.stream = !(getenv("NSX_ILU_STREAM") && atoi(getenv("NSX_ILU_STREAM")) == 0);
+  if (s.stream) {
+    IluStream st;
+    const int ept = getenv("NSX_ILU_EPT") ? std::max(1, std::min(4, atoi(getenv("NSX_ILU_EPT")))) : 2;
+    build_ilu_stream(g, bptr, std::max(1, blocks_per_wave), ncomp, 2, st, ept);
+    s.lanes_per_row = 0;
+    s.stream_ncomp = ncomp;
+    s.stream_epl = st.epl;
+    s.blocks_per_wave = blocks_per_wave;
+    s.n_waves = st.n_waves;
+    s.max_wave_rows = st.max_wave_rows;
+    s.n_slabs = st.n_slabs;
+    s.packed_ok = st.ok;
+    if (getenv("NSX_DEBUG"))
+      fprintf(stderr, "[nsx] ilu schedule: rows %d blocks %d max_rows %d levels(max) %d lane-owner stream: %d waves (%d blocks each), %d entries per tick, slabs %lld (max/wave %lld) fill %.2f, "
+                      "%.1f MB, in-block entries %lld, LDS rows/wave <= %d%s\n",
+              g.n_rows, nb, s.max_rows, s.max_levels, st.n_waves, blocks_per_wave, st.epl, (long long)st.n_slabs, (long long)st.max_wave_slabs,
+              (double)st.used_slots / (double)std::max<int64_t>(1, st.n_slabs * 64 * st.epl), 1e-6 * (double)st.n_slabs * 64 * (8 * st.epl + 4 * ilu_meta_words(st.epl)),
+              (long long)st.in_block_nnz, st.max_wave_rows, st.ok ? "" : " (too many: not used)");
+    s.pk_row_ptr.upload(st.row_ptr, h->stream);
+    s.pk_rows.upload(st.rows, h->stream);
+    {
+      std::vector<int32_t> slot(g.n_rows);
+      for (size_t k = 0; k < st.rows.size(); ++k) slot[st.rows[k]] = (int32_t)k;
+      s.pk_dinv_slot.upload(slot, h->stream);
+    }
+    s.pk_slab_ptr.upload(st.slab_ptr, h->stream);
+    s.pk_meta.upload(reinterpret_cast<const int32_t *>(st.meta.data()), st.meta.size(), h->stream);
+    s.pk_slot_of.upload(st.slot_of, h->stream);
+    s.pk_val.alloc((size_t)(st.n_slabs + ILU_STREAM_PAD) * 64 * st.epl);
+    s.pk_val.zero(h->stream);
+    s.pk_dinv.alloc(g.n_rows);
+  } else {
   const int LW = lanes_per_row, G = 64 / LW, BPW = std::max(1, blocks_per_wave);
   const bool allow_wide = allow_wide_rows && LW == 8;  // the pair sum is implemented for 8-lane groups (one 16-lane DPP row)
   s.lanes_per_row = LW;
@@ -355,6 +395,8 @@ void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> 
   s.pk_val.zero(h->stream);
   s.pk_dinv.alloc(g.n_rows);
 
+  }
+
   // ---- explicit block inverses.  Worth it when the blocks are few, small and deep: the dense matrices of all blocks
   // together (sum n_b^2) must not cost more traffic than the chain of the sparse sweep costs time.  Used for the Schur
   // matrix (one component, ~100-row blocks with ~95 dependency levels); the velocity blocks stay sparse.
@@ -498,12 +540,16 @@ static void refresh_rank_products(nsx_handle *h) {
 void ensure_schedules(nsx_handle *h) {
   if (!h->sched_dirty) return;
   if (!h->dist) build_blocked(h, h->gA.host, spmv_chunks(h), h->blkA);
+  const bool lanes = !(getenv("NSX_ILU_STREAM") && atoi(getenv("NSX_ILU_STREAM")) == 0);
   const int lwF = getenv("NSX_LW_F") ? atoi(getenv("NSX_LW_F")) : 8, lwS = getenv("NSX_LW_S") ? atoi(getenv("NSX_LW_S")) : 32;
-  const int bpwF = getenv("NSX_BPW_F") ? atoi(getenv("NSX_BPW_F")) : 1, bpwS = getenv("NSX_BPW_S") ? atoi(getenv("NSX_BPW_S")) : 1;
+  // blocks per wave: the lane-owner stream wants enough rows per wave to keep 64 lanes busy (~8 blocks of ~85 rows); the
+  // lane-group stream one block per wave
+  const int bpwF = getenv("NSX_BPW_F") ? atoi(getenv("NSX_BPW_F")) : (lanes ? std::max(1, std::min(64, (int)(680.0 * (h->rank_u_h.size() - 1) / std::max(1, h->N2) + 0.5))) : 1);
+  const int bpwS = getenv("NSX_BPW_S") ? atoi(getenv("NSX_BPW_S")) : 1;
   const bool wideF = !(getenv("NSX_WIDE") && atoi(getenv("NSX_WIDE")) == 0);
-  setup_ilu_schedule(h, h->gA.host, h->rank_u_h, h->schedF, lwF, bpwF, false, wideF && h->dim > 1);
+  setup_ilu_schedule(h, h->gA.host, h->rank_u_h, h->schedF, lwF, bpwF, false, wideF && h->dim > 1, h->dim);
   const bool denseS = !(getenv("NSX_DENSE_S") && atoi(getenv("NSX_DENSE_S")) == 0);
-  setup_ilu_schedule(h, h->gS.host, h->sblk_h.empty() ? h->rank_p_h : h->sblk_h, h->schedS, lwS, bpwS, denseS);
+  setup_ilu_schedule(h, h->gS.host, h->sblk_h.empty() ? h->rank_p_h : h->sblk_h, h->schedS, lwS, bpwS, denseS, false, 1);
   build_cg_plan(h);
   h->sched_dirty = false;
 }
@@ -545,6 +591,7 @@ int nsx_create(const nsx_params *p, nsx_handle **out) {
   auto *h = new nsx_handle;
   h->prm = *p;
   h->dim = p->dim;
+  if (getenv("NSX_GX_DROP_WG")) h->gx_drop_wg = atoi(getenv("NSX_GX_DROP_WG"));  // fault injection for the tests of the time-out fallbacks
   try {
     int ndev = 0;
     HIP_CHECK(hipGetDeviceCount(&ndev));

@@ -53,6 +53,27 @@ struct SolveResult {
   double last;
 };
 
+// Distributed runs: hold back the all-reduces of finished reductions for the lifetime of the scope and send them merged when
+// it ends (defer_reductions).  On unwinding (an exception between the two calls) nothing is sent any more, but the handle must
+// not stay in the deferring state: later solves would consume rank-local sums without an error.
+struct DeferScope {
+  nsx_handle *h;
+  bool active;
+  DeferScope(nsx_handle *h_, bool on) : h(h_), active(on) {
+    if (active) defer_reductions(h, true);
+  }
+  void release() {  // normal path: flush (one merged collective)
+    if (!active) return;
+    active = false;
+    defer_reductions(h, false);
+  }
+  ~DeferScope() {
+    if (!active) return;
+    h->defer_red = false;
+    h->pending_red.clear();
+  }
+};
+
 static int sc_check(int step, double value, double tol, int maxsteps) {  // SolverControl::check: 0 iterate, 1 success, 2 failure
   if (value <= tol) return 1;
   if (step >= maxsteps || std::isnan(value)) return 2;
@@ -245,7 +266,7 @@ static SolveResult cg(nsx_handle *h, const Op &A, double *x, const double *b, co
       // Distributed run: |g|^2 and the g.h of the next iteration are independent sums: their all-reduces are held back and
       // go out as ONE collective over the two adjacent slots (a latency, not a bandwidth, matter: 8 B or 16 KB cost the same).
       const bool batch = h->comm != nullptr;
-      if (batch) defer_reductions(h, true);
+      DeferScope defer(h, batch);
       cg_update(h, n.n, x, d.p(), g.p(), hv.p(), gh, S_DH, S_RES);  // alpha = gh / (d.h); x += alpha d; g += alpha h; res = |g|
       // The residual travels to the host while the GPU already applies the preconditioner of the NEXT iteration
       // (h = P g and g.h only touch temporaries): the host round trip hides behind that kernel instead of idling the
@@ -254,7 +275,7 @@ static SolveResult cg(nsx_handle *h, const Op &A, double *x, const double *b, co
       if (!batch) seq = publish_scalars(h, S_RES, 1);
       apply_P_dot(hv.p(), g.p(), gh_new);
       if (batch) {
-        defer_reductions(h, false);  // flushes: one all-reduce for S_RES and gh_new
+        defer.release();  // flushes: one all-reduce for S_RES and gh_new
         seq = publish_scalars(h, S_RES, 1);
       }
       double res2;
@@ -290,7 +311,7 @@ __global__ void k_same_and_keep(int n, const double *__restrict__ w, double *__r
 // Are the inputs of the Schur product the ones its current values were computed from?  (Bitwise comparison of the weight vector
 // on the device; the answer comes back through a mapped word behind one stream synchronisation.)
 static bool schur_inputs_unchanged(nsx_handle *h, int type) {
-  static const bool cache = !(getenv("NSX_SCHUR_CACHE") && atoi(getenv("NSX_SCHUR_CACHE")) == 0);
+  const bool cache = !(getenv("NSX_SCHUR_CACHE") && atoi(getenv("NSX_SCHUR_CACHE")) == 0);  // read per call: bench.py times both schedules on one handle
   const int n = h->len_u;  // owned + ghost weights
   volatile int *flag = (volatile int *)(h->pub_host + N_SLOTS + 4);
   const bool had = h->schur_valid && h->schur_type == type && (int)h->schur_w_prev.n == n;
@@ -298,8 +319,7 @@ static bool schur_inputs_unchanged(nsx_handle *h, int type) {
     h->schur_w_prev.alloc(n);
     comm_halo_u(h, h->schur_w.p);  // the comparison below covers what schur_numeric reads, ghosts included
     v_copy(h, n, h->schur_w_prev.p, h->schur_w.p);
-    h->schur_valid = true;
-    return false;
+    return false;  // schur_valid is set by the caller once the rebuild has gone through
   }
   comm_halo_u(h, h->schur_w.p);
   *flag = 0;
@@ -341,13 +361,35 @@ void prec_initialize(nsx_handle *h, int type) {
   // rebuilds both in every step.  Their only inputs are block(1,0) (assembled once) and the weights w; when w is bit for bit
   // the vector of the previous initialisation (Yosida: D = diag(M / deltat) and the Dirichlet mask do not change in time) the
   // product, its ILU(0) factors and the block inverses would come out bit for bit the same, and are kept.
+  // The kept values count as valid only once a rebuild has run to its end AND its factorisation reported no failure: a failed or
+  // interrupted rebuild must not be reused by the next initialisation with the same weights.  (k_same_and_keep has already
+  // overwritten schur_w_prev, so validity cannot be derived from the weights alone.)
   if (!schur_inputs_unchanged(h, type)) {
+    h->schur_valid = false;
+    h->schur_pending = true;  // confirmed by prec_confirm() behind the caller's synchronisation + ilu_check
     schur_numeric(h, h->schur_w.p);
     cg_pack_values(h);
     ilu_factor(h, h->gS, h->schedS, h->vSchur.p, h->luS.p, "ilu_factor_S");
     h->schur_type = type;
   }
   h->prec_ready = true;
+}
+
+// behind the stream synchronisation that follows prec_initialize: factorisation failures surface here (ilu_check throws), and only
+// a rebuild that got this far may be kept for later initialisations
+void prec_confirm(nsx_handle *h) {
+  try {
+    ilu_check(h);
+  } catch (...) {
+    h->schur_valid = false;
+    h->schur_pending = false;
+    h->prec_ready = false;
+    throw;
+  }
+  if (h->schur_pending) {
+    h->schur_pending = false;
+    h->schur_valid = true;
+  }
 }
 
 static void count(nsx_solve_stats *st, bool F, const SolveResult &r) {
@@ -451,9 +493,11 @@ void solve_time_step(nsx_handle *h, int type, double tol, double inner_rtol, int
   v_copy(h, h->len_blk, h->prev_sol.p, h->sol.p);  // previous_solution = solution (NS3D.cpp:555)
   HIP_CHECK(hipStreamSynchronize(h->stream));
   double t0 = now_s();
+  h->defer_red = false;  // a solve that unwound in the middle of a batched reduction must not leave the handle deferring
+  h->pending_red.clear();
   prec_initialize(h, type);  // NS3D.cpp:568-569
   HIP_CHECK(hipStreamSynchronize(h->stream));
-  ilu_check(h);
+  prec_confirm(h);
   st->t_prec = now_s() - t0;
   t0 = now_s();
   Op A = [h](double *d, const double *s) { spmv_saddle(h, s, d); };
@@ -466,6 +510,7 @@ void solve_time_step(nsx_handle *h, int type, double tol, double inner_rtol, int
   st->t_solve = now_s() - t0;
   st->outer_iterations = r.steps;
   st->final_residual = r.last;
+  st->persistent_fallbacks = h->n_persistent_fallbacks;
   if (r.status && st->status == 0) st->status = 1;
 }
 
@@ -511,7 +556,7 @@ int nsx_prec_initialize(nsx_handle *h, int prec_type) {
   NSX_API_BODY(h, {
     nsx::prec_initialize(h, prec_type);
     HIP_CHECK(hipStreamSynchronize(h->stream));
-    nsx::ilu_check(h);
+    nsx::prec_confirm(h);
   })
 }
 
@@ -525,7 +570,10 @@ int nsx_prec_vmult(nsx_handle *h, int prec_type, double inner_rtol, int inner_ma
     HIP_CHECK(hipMemcpyAsync(s.p(), src, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_CHECK(hipMemcpyAsync(d.p(), dst, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));  // aSIMPLE reads dst as initial guess
     if (stats) memset(stats, 0, sizeof(*stats));
+    h->defer_red = false;
+    h->pending_red.clear();
     nsx::prec_vmult(h, prec_type, inner_rtol, inner_maxiter, d.p(), s.p(), stats);
+    if (stats) stats->persistent_fallbacks = h->n_persistent_fallbacks;
     HIP_CHECK(hipMemcpyAsync(dst, d.p(), (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipStreamSynchronize(h->stream));
   })

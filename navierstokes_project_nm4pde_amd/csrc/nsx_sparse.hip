@@ -10,6 +10,7 @@
 // All kernels are HBM/L2-bandwidth bound; reductions inside a row use wavefront shuffles (64-wide waves, sub-groups of
 // 8/16/32/64 lanes per row chosen from the average row length).
 #include "nsx_internal.hpp"
+#include "nsx_ilu_lanes.hpp"
 
 namespace nsx {
 
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(ILU_WAVES * 64) void k_ilu_factor(const int32_t *__
                                                               const int32_t *__restrict__ diag, const double *__restrict__ a,
                                                               double *__restrict__ lu, const int32_t *__restrict__ slot_of,
                                                               double *__restrict__ pk_val, double *__restrict__ pk_dinv,
-                                                              int *__restrict__ err) {
+                                                              int *__restrict__ err, double pk_sign, const int32_t *__restrict__ dinv_slot) {
   __shared__ double wv[ILU_WAVES][ILU_MAXROW];
   const int blk = blockIdx.x, wave = threadIdx.x / 64, lane = threadIdx.x % 64;
   const int r0 = bptr[blk], r1 = bptr[blk + 1];
@@ -526,8 +527,8 @@ __global__ __launch_bounds__(ILU_WAVES * 64) void k_ilu_factor(const int32_t *__
         lu[p0 + t] = v;
         if (slot_of) {
           const int sl = slot_of[p0 + t];
-          if (sl >= 0) pk_val[sl] = v;
-          if (t == dpos) pk_dinv[i] = dinv;
+          if (sl >= 0) pk_val[sl] = pk_sign * v;  // the lane-owner stream adds value * x[col]: it stores -L and -U/d
+          if (t == dpos) pk_dinv[dinv_slot ? dinv_slot[i] : i] = dinv;
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -620,7 +621,7 @@ __global__ __launch_bounds__(ILU_WAVES * 64) void k_ilu_factor_small(const int32
                                                                     const int32_t *__restrict__ diag, const double *__restrict__ a,
                                                                     double *__restrict__ lu, const int32_t *__restrict__ slot_of,
                                                                     double *__restrict__ pk_val, double *__restrict__ pk_dinv,
-                                                                    int *__restrict__ err) {
+                                                                    int *__restrict__ err, double pk_sign, const int32_t *__restrict__ dinv_slot) {
   __shared__ double wv[ILU_WAVES][ILU_DENSE_ROWS];
   __shared__ short posv[ILU_WAVES][ILU_DENSE_ROWS];
   const int blk = blockIdx.x, wave = threadIdx.x / 64, lane = threadIdx.x % 64;
@@ -669,8 +670,8 @@ __global__ __launch_bounds__(ILU_WAVES * 64) void k_ilu_factor_small(const int32
         lu[p0 + t] = v;
         if (slot_of) {
           const int sl = slot_of[p0 + t];
-          if (sl >= 0) pk_val[sl] = v;
-          if (t == dpos) pk_dinv[i] = dinv;
+          if (sl >= 0) pk_val[sl] = pk_sign * v;  // the lane-owner stream adds value * x[col]: it stores -L and -U/d
+          if (t == dpos) pk_dinv[dinv_slot ? dinv_slot[i] : i] = dinv;
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -804,11 +805,11 @@ void ilu_factor(nsx_handle *h, const DevCsr &g, IluSchedule &s, const double *va
     } else if (small_ok && s.max_rows <= ILU_DENSE_ROWS)
       hipLaunchKernelGGL(k_ilu_factor_small, dim3(s.n_blocks), dim3(ILU_WAVES * 64), 0, h->stream, s.block_ptr.p, s.blk_lvl_off.p,
                          s.fwd_lvl_ptr.p, s.fwd_rows.p, g.rowptr.p, g.colind.p, g.diag.p, vals, lu, s.packed_ok ? s.pk_slot_of.p : nullptr,
-                         s.pk_val.p, s.pk_dinv.p, err);
+                         s.pk_val.p, s.pk_dinv.p, err, s.stream ? -1.0 : 1.0, s.stream ? s.pk_dinv_slot.p : nullptr);
     else
       hipLaunchKernelGGL(k_ilu_factor, dim3(s.n_blocks), dim3(ILU_WAVES * 64), 0, h->stream, s.block_ptr.p, s.blk_lvl_off.p, s.fwd_lvl_ptr.p,
                          s.fwd_rows.p, g.rowptr.p, g.colind.p, g.diag.p, vals, lu, s.packed_ok ? s.pk_slot_of.p : nullptr, s.pk_val.p,
-                         s.pk_dinv.p, err);
+                         s.pk_dinv.p, err, s.stream ? -1.0 : 1.0, s.stream ? s.pk_dinv_slot.p : nullptr);
   }
   if (s.dense) {
     LaunchScope ls(h, "ilu_invert", 8.0 * (double)s.dn_entries + 12.0 * g.nnz());
@@ -1059,6 +1060,117 @@ __global__ __launch_bounds__(64) void k_ilu_solve_packed(int bpw, const int32_t 
   }
 }
 
+// ---- lane-owner stream: device side in nsx_ilu_lanes.hpp (shared with tools/ilu_lanes_bench.hip), schedule in host/ilu_stream.hpp
+constexpr int LANES_K = 8;  // rows per lane and memory trip in the load / scale / store loops of k_ilu_solve_lanes
+
+template <int NCOMP, int E, int PF>
+__global__ __launch_bounds__(64) void k_ilu_solve_lanes(const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ rows,
+                                                        const int32_t *__restrict__ slab_ptr, const uint32_t *__restrict__ meta,
+                                                        const double *__restrict__ val, const double *__restrict__ dinv, const double *b, double *x,
+                                                        double *__restrict__ dot_partial) {
+  extern __shared__ double xs[];  // the only LDS of this kernel: the stream's addresses are absolute (nsx_ilu_lanes.hpp)
+  if ((uint32_t)(uintptr_t)(lds_f64 *)xs != 0u) return;  // cannot happen without static LDS; a wrong result is caught by every parity test
+  const int w = blockIdx.x;
+  const unsigned lane = threadIdx.x;
+  const int s0 = slab_ptr[2 * w], s1 = slab_ptr[2 * w + 1], s2 = slab_ptr[2 * w + 2];
+  const int rb = row_ptr[w], nr = row_ptr[w + 1] - rb;
+  // Flat loops over the wave's rows (LDS order), LANES_K rows per lane at a time with all loads of a stage issued back to back:
+  // a stage is ONE trip to memory, not one per row (the wave is alone on its SIMD: nothing else hides the latency)
+  constexpr int K = LANES_K;
+  for (int base = 0; base < nr; base += 64 * K) {
+    int idx[K];
+    double v[K][NCOMP];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int t = base + 64 * k + (int)lane;
+      idx[k] = t < nr ? rows[rb + t] : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) v[k][c] = idx[k] >= 0 ? b[(size_t)idx[k] * NCOMP + c] : 0.0;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if (idx[k] >= 0) {
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c) xs[(base + 64 * k + (int)lane) * NCOMP + c] = v[k][c];
+      }
+  }
+#pragma unroll
+  for (int c = 0; c < NCOMP; ++c) xs[(nr + lane) * NCOMP + c] = 0.0;  // the scratch rows of the idle slots
+  const uint32_t scratch = (uint32_t)(nr + lane) * (8u * NCOMP);
+  __builtin_amdgcn_wave_barrier();
+  lane_sweep<NCOMP, E, PF>(s0, s1, meta, val, lane, scratch);  // y = L^{-1} b
+  for (int base = 0; base < nr; base += 64 * K) {           // y *= D^{-1} (inverse pivots stored in the wave's row order)
+    double d[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int t = base + 64 * k + (int)lane;
+      d[k] = t < nr ? dinv[rb + t] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int t = base + 64 * k + (int)lane;
+      if (t < nr) {
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c) xs[t * NCOMP + c] *= d[k];
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  lane_sweep<NCOMP, E, PF>(s1, s2, meta, val, lane, scratch);  // x = U^{-1} y
+  double dot = 0.0;  // b . x over this wave's rows (CG's g.h right after the preconditioner, Prec.hpp:388 / SolverCG)
+  for (int base = 0; base < nr; base += 64 * K) {
+    int idx[K];
+    double bv[K][NCOMP];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int t = base + 64 * k + (int)lane;
+      idx[k] = t < nr ? rows[rb + t] : -1;
+    }
+    if (dot_partial) {
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c) bv[k][c] = idx[k] >= 0 ? b[(size_t)idx[k] * NCOMP + c] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if (idx[k] >= 0) {
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c) {
+          const double xv = xs[(base + 64 * k + (int)lane) * NCOMP + c];
+          if (dot_partial) dot += bv[k][c] * xv;
+          x[(size_t)idx[k] * NCOMP + c] = xv;
+        }
+      }
+  }
+  if (dot_partial) {
+    dot = lane_group_sum<64>(dot);
+    if (lane == 0) dot_partial[w] = dot;
+  }
+}
+
+template <int NCOMP>
+static void launch_lanes(nsx_handle *h, const IluSchedule &s, const double *b, double *x, double *dot_partial) {
+  const size_t shm = (size_t)(s.max_wave_rows + 64) * NCOMP * sizeof(double);
+  static const int pf = getenv("NSX_PF") ? atoi(getenv("NSX_PF")) : 8;
+#define NSX_GO(E_, PF_)                                                                                                                        \
+  hipLaunchKernelGGL((k_ilu_solve_lanes<NCOMP, E_, PF_>), dim3(s.n_waves), dim3(64), shm, h->stream, s.pk_row_ptr.p, s.pk_rows.p, s.pk_slab_ptr.p, \
+                     reinterpret_cast<const uint32_t *>(s.pk_meta.p), s.pk_val.p, s.pk_dinv.p, b, x, dot_partial)
+#define NSX_GO_E(E_)  \
+  if (pf == 4) NSX_GO(E_, 4); else NSX_GO(E_, 8)
+  switch (s.stream_epl) {
+    case 1: NSX_GO_E(1); break;
+    case 2: NSX_GO_E(2); break;
+    case 3: NSX_GO_E(3); break;
+    case 4: NSX_GO_E(4); break;
+    default: NSX_THROW(NSX_ERR_ARG, "internal: %d entries per tick", s.stream_epl);
+  }
+#undef NSX_GO_E
+#undef NSX_GO
+}
+
 template <int NCOMP, int LW>
 static void launch_packed(nsx_handle *h, const IluSchedule &s, const double *b, double *x, double *dot_partial) {
   const size_t shm = (size_t)s.max_wave_rows * NCOMP * sizeof(double);
@@ -1086,13 +1198,13 @@ static void launch_ilu_solve(nsx_handle *h, const DevCsr &g, const IluSchedule &
 bool ilu_solve(nsx_handle *h, const DevCsr &g, const IluSchedule &s, const double *lu, const double *b, double *x, int ncomp,
                const char *name, int dot_slot) {
   if (s.levelled) {
-    LaunchScope ls(h, name, 12.0 * g.nnz() + (double)g.n_rows() * (4 + 16.0 * ncomp));
+    LaunchScope ls(h, name, 12.0 * (double)s.in_block_nnz + (double)g.n_rows() * (4 + 16.0 * ncomp));
     if (ncomp == 1) ilu_solve_levelled<1>(h, g, s, lu, b, x);
     else if (ncomp == 2) ilu_solve_levelled<2>(h, g, s, lu, b, x);
     else ilu_solve_levelled<3>(h, g, s, lu, b, x);
     return false;
   }
-  const bool packed = s.packed_ok && (size_t)s.max_wave_rows * ncomp * sizeof(double) <= 64 * 1024;
+  const bool packed = s.packed_ok && (!s.stream || s.stream_ncomp == ncomp) && (size_t)(s.max_wave_rows + 64) * ncomp * sizeof(double) <= 64 * 1024;
   if (s.dense && ncomp == 1 && (size_t)s.max_rows * sizeof(double) <= 48 * 1024) {
     LaunchScope ls(h, name, 8.0 * (double)s.dn_entries + 16.0 * g.n_rows());
     const bool with_dot = dot_slot >= 0 && !h->comm && s.n_blocks >= 2 && s.n_blocks <= 512;  // a communicator needs equal counts on all ranks
@@ -1101,8 +1213,19 @@ bool ilu_solve(nsx_handle *h, const DevCsr &g, const IluSchedule &s, const doubl
     if (with_dot) after_reduction(h, dot_slot, s.n_blocks);
     return with_dot;
   }
-  // algorithmic bytes: the CSR factor once (12 B/entry) + rhs/solution vectors; the packed stream moves 768 B per slab
-  LaunchScope ls(h, name, 12.0 * g.nnz() + (double)g.n_rows() * (4 + 16.0 * ncomp));
+  // algorithmic bytes (nnz(L+U) * 12 + n * (4 + 8 + 8) per component set): what ONE application of a per-rank ILU(0)
+  // has to read -- the IN-BLOCK entries of the factor (diagonal included; couplings between ranks are dropped by Ifpack's
+  // local filter and are never touched) + right-hand side and solution.  The packed stream itself moves 768 B per slab.
+  LaunchScope ls(h, name, 12.0 * (double)s.in_block_nnz + (double)g.n_rows() * (4 + 16.0 * ncomp));
+  if (packed && s.stream) {
+    const bool with_dot = dot_slot >= 0 && !h->comm && s.n_waves >= 2 && s.n_waves <= 512;  // one partial sum per wave
+    double *dp = with_dot ? red_out(h, dot_slot, s.n_waves) : nullptr;
+    if (ncomp == 1) launch_lanes<1>(h, s, b, x, dp);
+    else if (ncomp == 2) launch_lanes<2>(h, s, b, x, dp);
+    else launch_lanes<3>(h, s, b, x, dp);
+    if (with_dot) after_reduction(h, dot_slot, s.n_waves);
+    return with_dot;
+  }
   if (packed) {
     const int lw = s.lanes_per_row;
     const bool with_dot = dot_slot >= 0 && !h->comm && s.n_waves >= 2 && s.n_waves <= 512;  // one partial sum per wave

@@ -71,6 +71,8 @@ def _lib():
         "nsxh_tables_dN2": (_f64p, [vp]),
         "nsxh_tables_N1": (_f64p, [vp]),
         "nsxh_tables_dN1": (_f64p, [vp]),
+        "nsxh_ilu_stream_stats": (C.c_int, [C.c_int, _i32p, _i32p, C.c_int, _i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
+        "nsxh_ilu_stream_apply": (C.c_int, [C.c_int, _i32p, _i32p, C.c_int, _i32p, C.c_int, C.c_int, C.c_int, C.c_int, _f64p, _f64p, _f64p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -279,3 +281,31 @@ class Tables:
         self.N1 = _arr(L.nsxh_tables_N1(h), (nq, n1), np.float64)
         self.dN1 = _arr(L.nsxh_tables_dN1(h), (nq, n1, dim), np.float64)
         L.nsxh_tables_free(h)
+
+
+def ilu_stream_stats(rowptr, colind, block_ptr, blocks_per_wave=8, ncomp=3, gap=2, entries_per_tick=1):
+    """Schedule statistics of the packed ILU(0) solve for a graph / block table (include/nsx_host.h: nsxh_ilu_stream_stats)."""
+    rp, ci, bp = (np.ascontiguousarray(a, dtype=np.int32) for a in (rowptr, colind, block_ptr))
+    out = (C.c_int64 * 6)()
+    rc = _lib().nsxh_ilu_stream_stats(len(rp) - 1, rp.ctypes.data_as(_i32p), ci.ctypes.data_as(_i32p), len(bp) - 1, bp.ctypes.data_as(_i32p),
+                                      int(blocks_per_wave), int(ncomp), int(gap), int(entries_per_tick), out)
+    if rc:
+        raise ValueError("nsxh_ilu_stream_stats failed (%d)" % rc)
+    keys = ("slabs", "max_wave_slabs", "in_block_nnz", "max_wave_rows", "waves", "used_slots")
+    d = dict(zip(keys, (int(v) for v in out)))
+    d["fill"] = d["used_slots"] / max(1, 64 * d["slabs"] * int(entries_per_tick))
+    d["stream_bytes"] = d["slabs"] * 64 * (8 * int(entries_per_tick) + 4 * ((int(entries_per_tick) + 2) // 2))
+    return d
+
+
+def ilu_stream_apply(rowptr, colind, block_ptr, lu, b, ncomp=1, blocks_per_wave=8, gap=2, entries_per_tick=1):
+    """Host replay of the packed ILU(0) solve stream (nsxh_ilu_stream_apply): x = U^-1 D^-1 L^-1 b per block."""
+    rp, ci, bp = (np.ascontiguousarray(a, dtype=np.int32) for a in (rowptr, colind, block_ptr))
+    lu, b = np.ascontiguousarray(lu, dtype=np.float64), np.ascontiguousarray(b, dtype=np.float64)
+    x = np.empty_like(b)
+    rc = _lib().nsxh_ilu_stream_apply(len(rp) - 1, rp.ctypes.data_as(_i32p), ci.ctypes.data_as(_i32p), len(bp) - 1, bp.ctypes.data_as(_i32p),
+                                      int(blocks_per_wave), int(ncomp), int(gap), int(entries_per_tick), lu.ctypes.data_as(_f64p), b.ctypes.data_as(_f64p),
+                                      x.ctypes.data_as(_f64p))
+    if rc:
+        raise ValueError("nsxh_ilu_stream_apply failed (%d)" % rc)
+    return x

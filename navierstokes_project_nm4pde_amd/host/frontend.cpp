@@ -26,6 +26,7 @@
 #include <sys/stat.h>
 
 #include "graph.hpp"
+#include "ilu_stream.hpp"
 
 namespace {
 
@@ -1424,3 +1425,45 @@ int nsxh_pressure_difference(const nsxh_dofs *d, const double *solution, const d
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------- test hooks: schedule of the packed ILU(0) solve
+// (host/ilu_stream.hpp is what the device library's set-up runs; these entry points let the CPU tests build a stream for any
+// graph / block table and replay it tick by tick against plain sequential sweeps)
+namespace {
+nsx::Csr csr_of(int n_rows, const int32_t *rowptr, const int32_t *colind) {
+  nsx::Csr g;
+  g.n_rows = g.n_cols = n_rows;
+  g.rowptr.assign(rowptr, rowptr + n_rows + 1);
+  g.colind.assign(colind, colind + rowptr[n_rows]);
+  return g;
+}
+}  // namespace
+
+extern "C" int nsxh_ilu_stream_stats(int n_rows, const int32_t *rowptr, const int32_t *colind, int n_blocks, const int32_t *block_ptr,
+                                     int blocks_per_wave, int ncomp, int gap, int entries_per_tick, int64_t out[6]) {
+  if (!rowptr || !colind || !block_ptr || !out || n_rows < 0 || n_blocks < 1 || ncomp < 1 || gap < 1 || entries_per_tick < 1 || entries_per_tick > 4) return -1;
+  try {
+    nsx::IluStream s;
+    nsx::build_ilu_stream(csr_of(n_rows, rowptr, colind), std::vector<int32_t>(block_ptr, block_ptr + n_blocks + 1), blocks_per_wave, ncomp, gap, s, entries_per_tick);
+    out[0] = s.n_slabs, out[1] = s.max_wave_slabs, out[2] = s.in_block_nnz, out[3] = s.max_wave_rows, out[4] = s.n_waves, out[5] = s.used_slots;
+    return s.ok ? 0 : -3;
+  } catch (const std::exception &) {
+    return -1;
+  }
+}
+
+extern "C" int nsxh_ilu_stream_apply(int n_rows, const int32_t *rowptr, const int32_t *colind, int n_blocks, const int32_t *block_ptr,
+                                     int blocks_per_wave, int ncomp, int gap, int entries_per_tick, const double *lu, const double *b, double *x) {
+  if (!rowptr || !colind || !block_ptr || !lu || !b || !x || ncomp < 1 || gap < 1 || entries_per_tick < 1 || entries_per_tick > 4) return -1;
+  try {
+    const nsx::Csr g = csr_of(n_rows, rowptr, colind);
+    const std::vector<int32_t> bptr(block_ptr, block_ptr + n_blocks + 1);
+    nsx::IluStream s;
+    nsx::build_ilu_stream(g, bptr, blocks_per_wave, ncomp, gap, s, entries_per_tick);
+    if (!s.ok) return -3;
+    nsx::replay_ilu_stream(g, bptr, s, lu, b, x);
+    return 0;
+  } catch (const std::exception &) {
+    return -1;
+  }
+}

@@ -22,7 +22,7 @@ API = [
     "nsx_set_rhs", "nsx_assemble", "nsx_assemble_time_step", "nsx_add_rhs", "nsx_apply_boundary_values",
     "nsx_solve_time_step", "nsx_prec_initialize", "nsx_prec_vmult", "nsx_system_vmult", "nsx_ilu_apply",
     "nsx_export_block", "nsx_schur_nnz", "nsx_schur_get", "nsx_scalar_graph_nnz", "nsx_scalar_graph", "nsx_ilu_get",
-    "nsx_profile_enable", "nsx_profile_reset", "nsx_profile_count", "nsx_profile_get", "nsx_comm_unique_id",
+    "nsx_profile_enable", "nsx_profile_reset", "nsx_profile_count", "nsx_profile_get", "nsx_persistent_state", "nsx_comm_unique_id",
     "nsx_comm_init", "nsx_comm_init_callbacks", "nsx_comm_counters", "nsx_set_mesh_distributed", "nsx_set_force_faces", "nsx_compute_forces",
 ]
 
@@ -38,7 +38,7 @@ class Params(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("outer_iterations", C.c_int), ("inner_F_iterations", C.c_int), ("inner_S_iterations", C.c_int),
                 ("n_F_solves", C.c_int), ("n_S_solves", C.c_int), ("final_residual", C.c_double),
-                ("t_prec", C.c_double), ("t_solve", C.c_double), ("status", C.c_int)]
+                ("t_prec", C.c_double), ("t_solve", C.c_double), ("status", C.c_int), ("persistent_fallbacks", C.c_int)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -85,6 +85,7 @@ def lib():
     L.nsx_profile_reset.argtypes = [vp]
     L.nsx_profile_count.argtypes = [vp]
     L.nsx_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), _f64p, _f64p]
+    L.nsx_persistent_state.argtypes = [vp, C.POINTER(C.c_int)]
     L.nsx_comm_unique_id.argtypes = [C.POINTER(C.c_uint8)]
     L.nsx_comm_init.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_uint8)]
     L.nsx_comm_init_callbacks.argtypes = [vp, C.c_int, C.c_int, ALLREDUCE_FN, EXCHANGE_FN, C.c_void_p]
@@ -187,6 +188,12 @@ class Nsx:
             dist.broadcast_object_list(box, src=0)
             ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
             self._ck(L.nsx_comm_init(self._h, rank, world, ident))
+
+    def persistent_state(self):
+        """dict: sweep / cg on their single-launch path, time-outs so far, non-empty mailbox words (nsx_persistent_state)"""
+        st = (C.c_int * 4)()
+        self._ck(self.L.nsx_persistent_state(self._h, st))
+        return {"sweep_persistent": bool(st[0]), "cg_persistent": bool(st[1]), "fallbacks": int(st[2]), "dirty_mailbox_words": int(st[3])}
 
     def comm_counters(self):
         """(all-reduces, ghost exchanges) issued since the communicator was set"""

@@ -230,18 +230,37 @@ def test_two_handles_driven_concurrently_on_one_device():
         assert np.abs(x - x_ref).max() < 1e-7 * np.abs(x_ref).max()
 
 
-def test_cooperative_launch_of_the_gram_schmidt_sweep(prob):
-    """NSX_MGS_COOP=1: the sweep goes through hipLaunchCooperativeKernel (launch-time size check); same results."""
-    res = []
-    for flag in ("0", "1"):
-        os.environ["NSX_MGS_COOP"] = flag
+def test_time_out_of_a_persistent_grid_falls_back_and_says_so():
+    """NSX_GX_DROP_WG=k (fault injection): workgroup k of a persistent grid never posts its partial sums, which is what a grid
+    that is not co-resident looks like.  The bounded waits must end the kernel without touching its vectors, the handle must
+    redo the operation on the launch-per-operation path, stay there, leave its mailboxes clean, count the event
+    (nsx_solve_stats::persistent_fallbacks, nsx_persistent_state) -- and end at the answer of a handle that never used the
+    persistent kernels.  One Gram-Schmidt sweep and one Schur CG time out (2 s each)."""
+    p = Problem("cylinder", 3, 2, n_sub=24, ordering="colour")
+    res = {}
+    for name, env in (("plain", {"NSX_MGS": "0", "NSX_CG_PERSISTENT": "0"}), ("healthy", {}), ("dropped", {"NSX_GX_DROP_WG": "1"})):
+        os.environ.update(env)
         try:
-            dev, _ = _assembled(prob)
+            dev, _ = _assembled(p)
             st = dev.solve_time_step(0, tol_abs=1e-10, inner_rtol=1e-8)
-            res.append((st, dev.solution_owned.copy()))
+            res[name] = (st, dev.solution_owned.copy(), dev.persistent_state())
+            if name == "dropped":  # the handle stays usable, and stays on the fallback path
+                st2 = dev.solve_time_step(0, tol_abs=1e-10, inner_rtol=1e-8)
+                assert st2["status"] == 0 and st2["persistent_fallbacks"] == 2
+                assert dev.persistent_state() == res[name][2]
             dev.close()
         finally:
-            os.environ.pop("NSX_MGS_COOP", None)
-    (s0, x0), (s1, x1) = res
-    assert s0["outer_iterations"] == s1["outer_iterations"] and s0["inner_F_iterations"] == s1["inner_F_iterations"]
-    assert np.abs(x0 - x1).max() < 1e-12 * np.abs(x0).max()
+            for k in env:
+                os.environ.pop(k, None)
+    (s0, x0, p0), (s1, x1, p1), (s2, x2, p2) = res["plain"], res["healthy"], res["dropped"]
+    assert p0 == {"sweep_persistent": False, "cg_persistent": False, "fallbacks": 0, "dirty_mailbox_words": 0}
+    assert p1 == {"sweep_persistent": True, "cg_persistent": True, "fallbacks": 0, "dirty_mailbox_words": 0}
+    assert p2 == {"sweep_persistent": False, "cg_persistent": False, "fallbacks": 2, "dirty_mailbox_words": 0}
+    assert s1["persistent_fallbacks"] == 0 and s2["persistent_fallbacks"] == 2
+    for s, x in ((s1, x1), (s2, x2)):
+        assert s["status"] == 0
+        for key in ("outer_iterations", "inner_F_iterations", "inner_S_iterations"):
+            assert abs(s0[key] - s[key]) <= max(1, 0.02 * s0[key]), key
+        assert np.abs(x0 - x).max() < 1e-9 * np.abs(x0).max()
+    # after the time-out the dropped handle runs the very kernels of the plain one
+    assert np.abs(x0 - x2).max() < 1e-11 * np.abs(x0).max()
