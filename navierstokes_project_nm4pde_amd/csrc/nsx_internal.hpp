@@ -118,23 +118,21 @@ struct IluSchedule {
   DevBuf<int32_t> blk_lvl_off;           // [n_blocks+1] offsets into fwd_lvl_ptr (levels per block), same for bwd
   DevBuf<int32_t> blk_lvl_off_b;
   int max_levels = 0;
-  // packed solve stream (one wave per group of blocks): slabs of 64 slots {value, meta}; meta = col | last_of_step<<15 | (dst_row+1)<<16 | row_uses_a_pair_of_groups<<31
-  int lanes_per_row = 8;
-  bool stream = false;          // true: lane-owner stream (host/ilu_stream.hpp, k_ilu_solve_lanes); false: the round-2 lane-group stream above
+  // packed solve stream (host/ilu_stream.hpp, k_ilu_solve_lanes): one wave per group of blocks, a lane owns a row for as many ticks
+  // as the row has in-block entries; slab t = tick t of the wave
+  int64_t in_block_nnz = 0;     // in-block entries of the factor, diagonal included: what one application has to read (algorithmic bytes)
   int stream_ncomp = 0;         // the stream holds LDS byte addresses: it is built for one number of interleaved right-hand sides
   int stream_epl = 1;           // entries of its row a lane takes per tick (NSX_ILU_EPT)
-  DevBuf<int32_t> pk_row_ptr, pk_rows;  // lane-owner stream: the rows of every wave in LDS order ([n_waves+1] offsets, global row ids)
-  DevBuf<int32_t> pk_dinv_slot;         // lane-owner stream: position of row i's inverse pivot in pk_dinv (wave order)
-  int64_t in_block_nnz = 0;     // in-block entries of the factor, diagonal included: what one application has to read (algorithmic bytes)
   int64_t n_slabs = 0;
   int blocks_per_wave = 1, n_waves = 0, max_wave_rows = 0;
-  bool packed_ok = false;
-  DevBuf<int32_t> pk_wave_blk;  // [n_waves*blocks_per_wave] blocks served by each wave (-1 = none)
+  bool packed_ok = false;       // false: a wave's rows do not fit 16-bit LDS addresses (few large blocks): workgroup-per-block kernel instead
+  DevBuf<int32_t> pk_row_ptr, pk_rows;  // the rows of every wave in LDS order ([n_waves+1] offsets, global row ids)
+  DevBuf<int32_t> pk_dinv_slot;         // position of row i's inverse pivot in pk_dinv (wave order)
   DevBuf<int32_t> pk_slab_ptr;  // [2*n_waves+1]: forward slabs, then backward slabs, per wave
-  DevBuf<int32_t> pk_meta;      // [n_slabs*64]
-  DevBuf<int32_t> pk_slot_of;   // [nnz]: slot of every in-block off-diagonal CSR entry, -1 otherwise
-  DevBuf<double> pk_val;        // [n_slabs*64] factor values in stream order (padding slots stay 0)
-  DevBuf<double> pk_dinv;       // [n_rows] inverse pivots
+  DevBuf<int32_t> pk_meta;      // [(n_slabs + pad) * 64 * meta words]
+  DevBuf<int32_t> pk_slot_of;   // [nnz]: position of every in-block off-diagonal CSR entry in pk_val, -1 otherwise
+  DevBuf<double> pk_val;        // [(n_slabs + pad) * 64 * stream_epl]: -L and -U/d in stream order (unused slots stay 0)
+  DevBuf<double> pk_dinv;       // [n_rows] inverse pivots in wave order
   // explicit inverses (k_ilu_invert / k_ilu_apply_dense): P_b = (L D U)^-1 of every block as a dense row-major n_b x n_b
   // matrix; the triangular solves become one dependency-free dense product per block
   bool dense = false;
@@ -323,8 +321,8 @@ struct LaunchScope {
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // ---- kernels / steps implemented across the .hip files
-void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> &block_ptr, IluSchedule &s, int lanes_per_row, int blocks_per_wave,
-                        bool allow_dense = false, bool allow_wide_rows = false, int ncomp = 1);
+void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> &block_ptr, IluSchedule &s, int blocks_per_wave, bool allow_dense = false,
+                        int ncomp = 1);
 void build_schur_graph(nsx_handle *h);
 void ensure_schedules(nsx_handle *h);  // (re)build the ILU schedules if the rank / Schur block tables changed
 

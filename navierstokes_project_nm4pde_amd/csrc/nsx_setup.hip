@@ -66,8 +66,7 @@ static void build_gather(nsx_handle *h, const Csr &g, int n_cells, int per_r, co
   gm.src.upload(src, h->stream);
 }
 
-void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> &bptr, IluSchedule &s, int lanes_per_row, int blocks_per_wave,
-                        bool allow_dense, bool allow_wide_rows, int ncomp) {
+void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> &bptr, IluSchedule &s, int blocks_per_wave, bool allow_dense, int ncomp) {
   const int nb = (int)bptr.size() - 1;
   s.n_blocks = nb;
   s.block_ptr_h = bptr;
@@ -166,20 +165,11 @@ void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> 
   s.blk_lvl_off.upload(off_f, h->stream);
   s.blk_lvl_off_b.upload(off_b, h->stream);
 
-  // ---- packed stream of the solve kernel (nsx_sparse.hip: k_ilu_solve_packed)
-  // One wave serves BPW blocks (deep blocks are spread over different waves, shallow ones fill them up).  Per sweep
-  // direction the rows of those blocks that have in-block entries are list-scheduled: a step = up to G = 64/LW rows
-  // whose dependencies were finished in earlier steps, longest remaining dependency chain first, LW lanes per row.
-  // A step occupies K slabs of 64 slots, slot (k, lane) = entry lane%LW + k*LW of row-group lane/LW.  Columns and
-  // destinations are row indices into the wave's LDS copy of x (its blocks back to back).
-  // Default: the lane-owner stream (host/ilu_stream.hpp, k_ilu_solve_lanes).  NSX_ILU_STREAM=0: the round-2 lane-group stream
-  // (LW lanes per row, DPP reductions per step: k_ilu_solve_packed).
-  s.stream = !(getenv("NSX_ILU_STREAM") && atoi(getenv("NSX_ILU_STREAM")) == 0);
-  if (s.stream) {
+  // ---- the packed stream of the solve kernel (host/ilu_stream.hpp, k_ilu_solve_lanes)
+  {
     IluStream st;
     const int ept = getenv("NSX_ILU_EPT") ? std::max(1, std::min(4, atoi(getenv("NSX_ILU_EPT")))) : 2;
     build_ilu_stream(g, bptr, std::max(1, blocks_per_wave), ncomp, 2, st, ept);
-    s.lanes_per_row = 0;
     s.stream_ncomp = ncomp;
     s.stream_epl = st.epl;
     s.blocks_per_wave = blocks_per_wave;
@@ -206,195 +196,6 @@ void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> 
     s.pk_val.alloc((size_t)(st.n_slabs + ILU_STREAM_PAD) * 64 * st.epl);
     s.pk_val.zero(h->stream);
     s.pk_dinv.alloc(g.n_rows);
-  } else {
-  const int LW = lanes_per_row, G = 64 / LW, BPW = std::max(1, blocks_per_wave);
-  const bool allow_wide = allow_wide_rows && LW == 8;  // the pair sum is implemented for 8-lane groups (one 16-lane DPP row)
-  s.lanes_per_row = LW;
-  s.blocks_per_wave = BPW;
-  const int nw = (nb + BPW - 1) / BPW;
-  s.n_waves = nw;
-  std::vector<int32_t> wave_blk((size_t)nw * BPW, -1);
-  {
-    std::vector<int32_t> order(nb), depth(nb);
-    for (int b = 0; b < nb; ++b) depth[b] = (off_f[b + 1] - off_f[b]) + (off_b[b + 1] - off_b[b]);
-    for (int b = 0; b < nb; ++b) order[b] = b;
-    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return depth[x] > depth[y]; });
-    for (int p = 0; p < BPW; ++p)
-      for (int w = 0; w < nw; ++w) {
-        const int64_t idx = (int64_t)p * nw + ((p & 1) ? nw - 1 - w : w);
-        if (idx < nb) wave_blk[(size_t)w * BPW + p] = order[idx];
-      }
-  }
-  s.max_wave_rows = 0;
-  std::vector<int32_t> slab_ptr(2 * (size_t)nw + 1, 0), meta, slot_of(g.nnz(), -1);
-  std::vector<int32_t> xoff(g.n_rows, 0);  // LDS row index of every row (within its wave)
-  std::vector<int32_t> height(g.n_rows), indeg(g.n_rows), pend(g.n_rows);
-  int64_t n_steps = 0, max_steps = 0;
-  for (int w = 0; w < nw; ++w) {
-    int wr = 0;
-    for (int p = 0; p < BPW; ++p) {
-      const int b = wave_blk[(size_t)w * BPW + p];
-      if (b < 0) continue;
-      for (int i = bptr[b]; i < bptr[b + 1]; ++i) xoff[i] = wr++;
-    }
-    s.max_wave_rows = std::max(s.max_wave_rows, wr);
-    int64_t wave_steps = 0;
-    for (int dir = 0; dir < 2; ++dir) {
-      const bool fwd = dir == 0;
-      auto in_part = [&](int i, int j, int r0, int r1) { return fwd ? (j >= r0 && j < i) : (j > i && j < r1); };
-      // remaining chain length of every row (dependents first) and the number of unfinished dependencies
-      std::vector<std::pair<int32_t, int32_t>> ready;  // (height, row)
-      std::vector<int32_t> work;
-      for (int p = 0; p < BPW; ++p) {
-        const int b = wave_blk[(size_t)w * BPW + p];
-        if (b < 0) continue;
-        const int r0 = bptr[b], r1 = bptr[b + 1];
-        for (int i = r0; i < r1; ++i) height[i] = 0, indeg[i] = 0, pend[i] = 0;
-        for (int t = 0; t < r1 - r0; ++t) {
-          const int i = fwd ? r1 - 1 - t : r0 + t;  // dependents before their dependencies
-          for (int q = g.rowptr[i]; q < g.rowptr[i + 1]; ++q) {
-            const int j = g.colind[q];
-            if (!in_part(i, j, r0, r1)) continue;
-            height[j] = std::max(height[j], height[i] + 1);
-            indeg[i]++;
-          }
-        }
-        // rows without in-block entries are final from the start: they do not count as dependencies
-        for (int i = r0; i < r1; ++i) {
-          if (indeg[i] == 0) continue;
-          for (int q = g.rowptr[i]; q < g.rowptr[i + 1]; ++q) {
-            const int j = g.colind[q];
-            if (in_part(i, j, r0, r1) && indeg[j] > 0) pend[i]++;
-          }
-          work.push_back(i);
-        }
-      }
-      for (int i : work)
-        if (pend[i] == 0) ready.push_back({height[i], i});
-      size_t done = 0;
-      std::vector<int32_t> step_rows;
-      while (done < work.size()) {
-        if (ready.empty()) NSX_THROW(NSX_ERR_ARG, "internal: ILU schedule has a dependency cycle");
-        // pick rows with the longest remaining chains first (ties: lowest row index, deterministic) until the G lane groups
-        // of the step are taken.  A row with more than LW entries may take an aligned PAIR of groups (allow_wide: the
-        // kernel adds the two group sums with one more DPP stage), so that it does not force a second slab on everybody.
-        std::sort(ready.begin(), ready.end(), [](const std::pair<int32_t, int32_t> &x, const std::pair<int32_t, int32_t> &y) {
-          return x.first != y.first ? x.first > y.first : x.second < y.second;
-        });
-        std::vector<int32_t> wide_rows, narrow_rows;
-        std::vector<char> taken(ready.size(), 0);
-        int used = 0;
-        // slabs a row needs on the lanes it would get: the step costs the maximum over its rows, so a step should hold rows of
-        // one size class.  The most urgent row sets the class; rows of other classes are taken only if groups stay free and
-        // their remaining chain is as long as the most urgent row's (they would hold up the wave otherwise).
-        auto slabs_of = [&](int i) {
-          const bool wide = allow_wide && G >= 2 && indeg[i] > LW;
-          return (indeg[i] + (wide ? 2 * LW : LW) - 1) / (wide ? 2 * LW : LW);
-        };
-        static const bool by_class = !(getenv("NSX_ILU_CLASS") && atoi(getenv("NSX_ILU_CLASS")) == 0);  // 140.6 k -> 137.2 k slabs, 35.8 -> 35.0 us
-        const int k_star = ready.empty() ? 1 : slabs_of(ready[0].second), h_star = ready.empty() ? 0 : ready[0].first;
-        for (int pass = 0; pass < (by_class ? 2 : 1); ++pass)
-          for (size_t k = 0; k < ready.size() && used < G; ++k) {
-            if (taken[k]) continue;
-            const int i = ready[k].second;
-            if (by_class && pass == 0 && slabs_of(i) != k_star) continue;
-            if (by_class && pass == 1 && ready[k].first < h_star && slabs_of(i) > k_star) continue;  // a longer row would cost everybody a slab
-            const bool wide = allow_wide && G >= 2 && indeg[i] > LW;
-            const int need = wide ? 2 : 1;
-            if (used + need > G) continue;
-            (wide ? wide_rows : narrow_rows).push_back(i);
-            used += need;
-            taken[k] = 1;
-          }
-        {
-          size_t o = 0;
-          for (size_t k = 0; k < ready.size(); ++k)
-            if (!taken[k]) ready[o++] = ready[k];
-          ready.resize(o);
-        }
-        step_rows.clear();
-        int row_of_group[64], sub_of_group[64];  // G <= 64
-        for (int gi = 0; gi < G; ++gi) row_of_group[gi] = -1, sub_of_group[gi] = 0;
-        for (size_t k = 0; k < wide_rows.size(); ++k) {
-          row_of_group[2 * k] = row_of_group[2 * k + 1] = (int)step_rows.size();
-          sub_of_group[2 * k + 1] = 1;
-          step_rows.push_back(wide_rows[k]);
-        }
-        for (size_t k = 0; k < narrow_rows.size(); ++k) {
-          row_of_group[2 * wide_rows.size() + k] = (int)step_rows.size();
-          step_rows.push_back(narrow_rows[k]);
-        }
-        const int ng = (int)step_rows.size(), n_wide = (int)wide_rows.size();
-        std::vector<std::vector<int32_t>> ent(ng);
-        int K = 1;
-        for (int r = 0; r < ng; ++r) {
-          const int i = step_rows[r];
-          const int b = (int)(std::upper_bound(bptr.begin(), bptr.end(), i) - bptr.begin()) - 1;
-          for (int q = g.rowptr[i]; q < g.rowptr[i + 1]; ++q)
-            if (in_part(i, g.colind[q], bptr[b], bptr[b + 1])) ent[r].push_back(q);
-          const int lanes = r < n_wide ? 2 * LW : LW;
-          K = std::max(K, ((int)ent[r].size() + lanes - 1) / lanes);
-        }
-        for (int k = 0; k < K; ++k) {
-          const size_t base = meta.size();
-          meta.resize(base + 64, 0);
-          for (int lane = 0; lane < 64; ++lane) {
-            const int gi = lane / LW, l = lane % LW, r = row_of_group[gi];
-            int32_t m = (k == K - 1) ? 0x8000 : 0;
-            if (r >= 0) {
-              const bool wide = r < n_wide;
-              const size_t e = wide ? (size_t)sub_of_group[gi] * LW + l + (size_t)k * 2 * LW : (size_t)l + (size_t)k * LW;
-              if (e < ent[r].size()) {
-                const int q = ent[r][e];
-                m |= xoff[g.colind[q]];
-                slot_of[q] = (int32_t)(base + lane);
-              }
-              // destination row (and the pair flag) in every lane of the row's FIRST group
-              if (k == K - 1 && sub_of_group[gi] == 0) m |= ((xoff[step_rows[r]] + 1) << 16) | (wide ? (int32_t)0x80000000 : 0);
-            }
-            meta[base + lane] = m;
-          }
-        }
-        ++wave_steps;
-        done += ng;
-        // release the dependents of the rows just scheduled (available from the next step on)
-        for (int gi = 0; gi < ng; ++gi) {
-          const int j = step_rows[gi];
-          const int b = (int)(std::upper_bound(bptr.begin(), bptr.end(), j) - bptr.begin()) - 1;
-          const int r0 = bptr[b], r1 = bptr[b + 1];
-          // the graph is structurally symmetric (FE pattern, B B^T): dependents of j = the other triangle of row j
-          for (int q = g.rowptr[j]; q < g.rowptr[j + 1]; ++q) {
-            const int i = g.colind[q];
-            if (!(fwd ? (i > j && i < r1) : (i < j && i >= r0))) continue;
-            if (indeg[i] == 0) continue;
-            if (--pend[i] == 0) ready.push_back({height[i], i});
-          }
-        }
-      }
-      slab_ptr[2 * (size_t)w + 1 + dir] = (int32_t)(meta.size() / 64);
-    }
-    n_steps += wave_steps;
-    max_steps = std::max(max_steps, wave_steps);
-  }
-  s.n_slabs = (int64_t)meta.size() / 64;
-  s.packed_ok = s.max_wave_rows <= 32766;  // 15-bit column and destination fields
-  if (getenv("NSX_DEBUG")) {
-    int64_t max_slabs = 0, used = 0;
-    for (int w = 0; w < nw; ++w) max_slabs = std::max<int64_t>(max_slabs, slab_ptr[2 * w + 2] - slab_ptr[2 * w]);
-    for (int32_t v : slot_of) used += v >= 0;
-    fprintf(stderr, "[nsx] ilu schedule: rows %d blocks %d max_rows %d levels(max) %d LW %d BPW %d waves %d slabs %lld (max/wave %lld) steps %lld (max/wave %lld) fill %.2f\n",
-            g.n_rows, nb, s.max_rows, s.max_levels, LW, BPW, nw, (long long)s.n_slabs, (long long)max_slabs, (long long)n_steps, (long long)max_steps,
-            (double)used / (double)std::max<int64_t>(1, s.n_slabs * 64));
-  }
-  s.pk_wave_blk.upload(wave_blk, h->stream);
-
-  s.pk_slab_ptr.upload(slab_ptr, h->stream);
-  s.pk_meta.upload(meta, h->stream);
-  s.pk_slot_of.upload(slot_of, h->stream);
-  s.pk_val.alloc(meta.size());
-  s.pk_val.zero(h->stream);
-  s.pk_dinv.alloc(g.n_rows);
-
   }
 
   // ---- explicit block inverses.  Worth it when the blocks are few, small and deep: the dense matrices of all blocks
@@ -540,16 +341,15 @@ static void refresh_rank_products(nsx_handle *h) {
 void ensure_schedules(nsx_handle *h) {
   if (!h->sched_dirty) return;
   if (!h->dist) build_blocked(h, h->gA.host, spmv_chunks(h), h->blkA);
-  const bool lanes = !(getenv("NSX_ILU_STREAM") && atoi(getenv("NSX_ILU_STREAM")) == 0);
-  const int lwF = getenv("NSX_LW_F") ? atoi(getenv("NSX_LW_F")) : 8, lwS = getenv("NSX_LW_S") ? atoi(getenv("NSX_LW_S")) : 32;
-  // blocks per wave: the lane-owner stream wants enough rows per wave to keep 64 lanes busy (~8 blocks of ~85 rows); the
-  // lane-group stream one block per wave
-  const int bpwF = getenv("NSX_BPW_F") ? atoi(getenv("NSX_BPW_F")) : (lanes ? std::max(1, std::min(64, (int)(680.0 * (h->rank_u_h.size() - 1) / std::max(1, h->N2) + 0.5))) : 1);
-  const int bpwS = getenv("NSX_BPW_S") ? atoi(getenv("NSX_BPW_S")) : 1;
-  const bool wideF = !(getenv("NSX_WIDE") && atoi(getenv("NSX_WIDE")) == 0);
-  setup_ilu_schedule(h, h->gA.host, h->rank_u_h, h->schedF, lwF, bpwF, false, wideF && h->dim > 1, h->dim);
+  // blocks per wave: enough rows to keep the 64 lanes of the lane-owner stream busy (~680 rows: 8 blocks of ~85 rows measured
+  // best at 1 M DoF / 4096 ranks: fewer blocks per wave leave idle slots in the stream, more leave too few waves)
+  auto blocks_per_wave = [](int n_rows, size_t n_blocks) { return std::max(1, std::min(64, (int)(680.0 * (double)n_blocks / std::max(1, n_rows) + 0.5))); };
+  const std::vector<int32_t> &sb = h->sblk_h.empty() ? h->rank_p_h : h->sblk_h;
+  const int bpwF = getenv("NSX_BPW_F") ? atoi(getenv("NSX_BPW_F")) : blocks_per_wave(h->N2, h->rank_u_h.size() - 1);
+  const int bpwS = getenv("NSX_BPW_S") ? atoi(getenv("NSX_BPW_S")) : blocks_per_wave(h->NP, sb.size() - 1);
+  setup_ilu_schedule(h, h->gA.host, h->rank_u_h, h->schedF, bpwF, false, h->dim);
   const bool denseS = !(getenv("NSX_DENSE_S") && atoi(getenv("NSX_DENSE_S")) == 0);
-  setup_ilu_schedule(h, h->gS.host, h->sblk_h.empty() ? h->rank_p_h : h->sblk_h, h->schedS, lwS, bpwS, denseS, false, 1);
+  setup_ilu_schedule(h, h->gS.host, sb, h->schedS, bpwS, denseS, 1);
   build_cg_plan(h);
   h->sched_dirty = false;
 }

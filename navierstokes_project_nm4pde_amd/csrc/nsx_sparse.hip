@@ -478,7 +478,7 @@ __global__ __launch_bounds__(ILU_WAVES * 64) void k_ilu_factor(const int32_t *__
                                                               const int32_t *__restrict__ diag, const double *__restrict__ a,
                                                               double *__restrict__ lu, const int32_t *__restrict__ slot_of,
                                                               double *__restrict__ pk_val, double *__restrict__ pk_dinv,
-                                                              int *__restrict__ err, double pk_sign, const int32_t *__restrict__ dinv_slot) {
+                                                              int *__restrict__ err, const int32_t *__restrict__ dinv_slot) {
   __shared__ double wv[ILU_WAVES][ILU_MAXROW];
   const int blk = blockIdx.x, wave = threadIdx.x / 64, lane = threadIdx.x % 64;
   const int r0 = bptr[blk], r1 = bptr[blk + 1];
@@ -527,8 +527,8 @@ __global__ __launch_bounds__(ILU_WAVES * 64) void k_ilu_factor(const int32_t *__
         lu[p0 + t] = v;
         if (slot_of) {
           const int sl = slot_of[p0 + t];
-          if (sl >= 0) pk_val[sl] = pk_sign * v;  // the lane-owner stream adds value * x[col]: it stores -L and -U/d
-          if (t == dpos) pk_dinv[dinv_slot ? dinv_slot[i] : i] = dinv;
+          if (sl >= 0) pk_val[sl] = -v;  // the stream adds value * x[col]: it stores -L and -U/d
+          if (t == dpos) pk_dinv[dinv_slot[i]] = dinv;
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(ILU_WAVES * 64) void k_ilu_factor_small(const int32
                                                                     const int32_t *__restrict__ diag, const double *__restrict__ a,
                                                                     double *__restrict__ lu, const int32_t *__restrict__ slot_of,
                                                                     double *__restrict__ pk_val, double *__restrict__ pk_dinv,
-                                                                    int *__restrict__ err, double pk_sign, const int32_t *__restrict__ dinv_slot) {
+                                                                    int *__restrict__ err, const int32_t *__restrict__ dinv_slot) {
   __shared__ double wv[ILU_WAVES][ILU_DENSE_ROWS];
   __shared__ short posv[ILU_WAVES][ILU_DENSE_ROWS];
   const int blk = blockIdx.x, wave = threadIdx.x / 64, lane = threadIdx.x % 64;
@@ -670,8 +670,8 @@ __global__ __launch_bounds__(ILU_WAVES * 64) void k_ilu_factor_small(const int32
         lu[p0 + t] = v;
         if (slot_of) {
           const int sl = slot_of[p0 + t];
-          if (sl >= 0) pk_val[sl] = pk_sign * v;  // the lane-owner stream adds value * x[col]: it stores -L and -U/d
-          if (t == dpos) pk_dinv[dinv_slot ? dinv_slot[i] : i] = dinv;
+          if (sl >= 0) pk_val[sl] = -v;  // the stream adds value * x[col]: it stores -L and -U/d
+          if (t == dpos) pk_dinv[dinv_slot[i]] = dinv;
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -805,11 +805,11 @@ void ilu_factor(nsx_handle *h, const DevCsr &g, IluSchedule &s, const double *va
     } else if (small_ok && s.max_rows <= ILU_DENSE_ROWS)
       hipLaunchKernelGGL(k_ilu_factor_small, dim3(s.n_blocks), dim3(ILU_WAVES * 64), 0, h->stream, s.block_ptr.p, s.blk_lvl_off.p,
                          s.fwd_lvl_ptr.p, s.fwd_rows.p, g.rowptr.p, g.colind.p, g.diag.p, vals, lu, s.packed_ok ? s.pk_slot_of.p : nullptr,
-                         s.pk_val.p, s.pk_dinv.p, err, s.stream ? -1.0 : 1.0, s.stream ? s.pk_dinv_slot.p : nullptr);
+                         s.pk_val.p, s.pk_dinv.p, err, s.pk_dinv_slot.p);
     else
       hipLaunchKernelGGL(k_ilu_factor, dim3(s.n_blocks), dim3(ILU_WAVES * 64), 0, h->stream, s.block_ptr.p, s.blk_lvl_off.p, s.fwd_lvl_ptr.p,
                          s.fwd_rows.p, g.rowptr.p, g.colind.p, g.diag.p, vals, lu, s.packed_ok ? s.pk_slot_of.p : nullptr, s.pk_val.p,
-                         s.pk_dinv.p, err, s.stream ? -1.0 : 1.0, s.stream ? s.pk_dinv_slot.p : nullptr);
+                         s.pk_dinv.p, err, s.pk_dinv_slot.p);
   }
   if (s.dense) {
     LaunchScope ls(h, "ilu_invert", 8.0 * (double)s.dn_entries + 12.0 * g.nnz());
@@ -892,172 +892,6 @@ __global__ __launch_bounds__(256) void k_ilu_solve(const int32_t *__restrict__ b
   }
   if (USE_LDS)
     for (int t = threadIdx.x; t < nloc * NCOMP; t += 256) x[(size_t)r0 * NCOMP + t] = xs[t];
-}
-
-// ---- packed wave-per-block solve -------------------------------------------------------------------------------
-// One WAVE per group of rank blocks (nsx_setup.hip), their part of x in LDS, no workgroup barriers.  The factor is read as a linear
-// stream of 64-slot slabs {value, meta} laid out at setup in exactly the order the wave consumes it (nsx_setup.hip),
-// so the only dependent chain per step is LDS gather -> FMA -> LW-lane DPP reduction -> LDS update; the global loads
-// are address-independent of x and are prefetched PF slabs ahead in registers.
-// Step end: sum the NCOMP partial sums over the LW lanes of each row group and update x.  After the two quad stages the
-// four lanes of a quad hold identical sums, so lane q of every quad keeps component q and the remaining stages run on
-// ONE register instead of NCOMP; they use row rotations by multiples of 4 (which preserve the position inside a quad, unlike
-// the mirror modes).  Lanes 0..NCOMP-1 of a group end up with the totals of components 0..NCOMP-1 and each updates its
-// own entry of x (the stream stores the destination row in lanes 0..3 of a group).
-template <int NCOMP, int LW>
-__device__ __forceinline__ void packed_slab(double v, int mk, double (&acc)[NCOMP], double *xs, int lane) {
-  // last slab of the step: the flag is set in every lane; reading it from lane 0 makes the branch a scalar one (no
-  // exec-mask bookkeeping around the reduction)
-  const bool last = (__builtin_amdgcn_readfirstlane(mk) & 0x8000) != 0;
-  const int dst = (mk >> 16) & 0x7fff, l = lane % LW;  // bit 31: the row occupies this group AND the next one (LW == 8)
-  constexpr bool MERGED = NCOMP > 1 && NCOMP <= 4 && LW >= 8;
-  constexpr bool SCALAR = NCOMP == 1 && LW >= 4;
-  // lane of the group that ends up with the sum in the one-component path: lane 0 up to 16 lanes per row (all lanes of
-  // a DPP row hold it), the first lane of the LAST row of the group beyond (the row broadcasts accumulate upwards)
-  constexpr int WL = LW <= 16 ? 0 : LW - 16;
-  // the entry of x this lane will update is read FIRST: its LDS latency overlaps the gather + FMA + reduction chain
-  double old = 0.0;
-  int widx = 0;
-  const bool writer = last && dst && (MERGED ? l < NCOMP : (SCALAR ? l == WL : l == 0));
-  if (MERGED) {
-    widx = (dst - 1) * NCOMP + l;
-    if (writer) old = xs[widx];
-  } else if (SCALAR) {
-    widx = dst - 1;
-    if (writer) old = xs[widx];
-  }
-  const double *xj = xs + (mk & 0x7fff) * NCOMP;
-#pragma unroll
-  for (int c = 0; c < NCOMP; ++c) acc[c] += v * xj[c];
-  if (last) {
-    if constexpr (MERGED) {
-      double r[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int c = 0; c < NCOMP; ++c) {
-        double t = acc[c];
-        t += dpp_f64<0xB1>(t);  // quad_perm [1,0,3,2]
-        t += dpp_f64<0x4E>(t);  // quad_perm [2,3,0,1]
-        r[c] = t;
-      }
-      // lane q of a quad keeps component q: selected half by half with integer conditional moves (written as a ?: on the
-      // doubles, hipcc turns the selection into nested divergent branches)
-      const int q = lane & 3;
-      int wlo = __double2loint(r[0]), whi = __double2hiint(r[0]);
-#pragma unroll
-      for (int c = 1; c < NCOMP; ++c) {
-        wlo = q == c ? __double2loint(r[c]) : wlo;
-        whi = q == c ? __double2hiint(r[c]) : whi;
-      }
-      double w = __hiloint2double(whi, wlo);
-      // row_ror:n hands lane i the value of lane (i - n) mod 16 of its 16-lane row
-      if (LW == 8) {
-        w += dpp_f64<0x12C>(w);                      // row_ror:12: lane i += lane i+4 (the second quad of the 8-lane group)
-        const double pair = w + dpp_f64<0x128>(w);   // row_ror:8: + the sum of the neighbouring group (lanes i+8)
-        w = mk < 0 ? pair : w;
-      }
-      if (LW >= 16) w += dpp_f64<0x124>(w);  // row_ror:4 then row_ror:8: every lane ends with the sum of its residue class mod 4
-      if (LW >= 16) w += dpp_f64<0x128>(w);
-      if (LW >= 32) w += __shfl_xor(w, 16, 64);
-      if (LW >= 64) w += __shfl_xor(w, 32, 64);
-      if (writer) xs[widx] = old - w;
-    } else if constexpr (SCALAR) {
-      double t = acc[0];
-      t += dpp_f64<0xB1>(t);
-      t += dpp_f64<0x4E>(t);
-      if (LW >= 8) t += dpp_f64<0x141>(t);   // row_half_mirror
-      if (LW >= 16) t += dpp_f64<0x140>(t);  // row_mirror: every lane of a 16-lane row holds the row's sum
-      if (LW >= 32) t += dpp_f64_rows<0x142, 0xA>(t);  // row_bcast:15 into rows 1 and 3: they now hold the sums of rows 0+1 / 2+3
-      if (LW >= 64) t += dpp_f64_rows<0x143, 0xC>(t);  // row_bcast:31 into rows 2 and 3: row 3 holds the wave's sum
-      if (writer) xs[widx] = old - t;
-    } else {
-#pragma unroll
-      for (int c = 0; c < NCOMP; ++c) acc[c] = lane_group_sum<LW>(acc[c]);
-      if (writer) {
-        double *xi = xs + (dst - 1) * NCOMP;
-#pragma unroll
-        for (int c = 0; c < NCOMP; ++c) xi[c] -= acc[c];
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < NCOMP; ++c) acc[c] = 0.0;
-  }
-}
-
-// Two register sets (A/B) of PF slabs each: while one set is consumed the other is in flight; no register moves,
-// so hipcc can wait with a counted vmcnt on exactly the older set.
-template <int NCOMP, int LW, int PF>
-__device__ __forceinline__ void packed_sweep(int sa, int sb, const int32_t *__restrict__ meta, const double *__restrict__ val,
-                                             double *xs, int lane) {
-  double va[PF], vb[PF];
-  int ma[PF], mb[PF];
-  double acc[NCOMP];
-#pragma unroll
-  for (int c = 0; c < NCOMP; ++c) acc[c] = 0.0;
-#define NSX_LOAD(V, M, S0)                                      \
-  _Pragma("unroll") for (int k = 0; k < PF; ++k) {              \
-    const int s_ = (S0) + k;                                    \
-    const bool ok_ = s_ < sb;                                   \
-    V[k] = ok_ ? ld_stream<4>(val + (size_t)s_ * 64 + lane) : 0.0; \
-    M[k] = ok_ ? ld_stream<4>(meta + (size_t)s_ * 64 + lane) : 0;  \
-  }
-#define NSX_USE(V, M, S0)                                       \
-  _Pragma("unroll") for (int k = 0; k < PF; ++k)                \
-    if ((S0) + k < sb) packed_slab<NCOMP, LW>(V[k], M[k], acc, xs, lane);
-  NSX_LOAD(va, ma, sa)
-  for (int s0 = sa; s0 < sb; s0 += 2 * PF) {
-    NSX_LOAD(vb, mb, s0 + PF)
-    NSX_USE(va, ma, s0)
-    NSX_LOAD(va, ma, s0 + 2 * PF)
-    NSX_USE(vb, mb, s0 + PF)
-  }
-#undef NSX_LOAD
-#undef NSX_USE
-}
-
-template <int NCOMP, int LW, int PF>
-__global__ __launch_bounds__(64) void k_ilu_solve_packed(int bpw, const int32_t *__restrict__ wave_blk, const int32_t *__restrict__ bptr,
-                                                         const int32_t *__restrict__ slab_ptr, const int32_t *__restrict__ meta,
-                                                         const double *__restrict__ val, const double *__restrict__ dinv,
-                                                         const double *b, double *x, double *__restrict__ dot_partial) {
-  extern __shared__ double xs[];
-  const int w = blockIdx.x, lane = threadIdx.x;
-  const int s0 = slab_ptr[2 * w], s1 = slab_ptr[2 * w + 1], s2 = slab_ptr[2 * w + 2];
-  for (int p = 0, xo = 0; p < bpw; ++p) {
-    const int blk = wave_blk[w * bpw + p];
-    if (blk < 0) continue;
-    const int r0 = bptr[blk], nloc = bptr[blk + 1] - r0;
-    for (int t = lane; t < nloc * NCOMP; t += 64) xs[xo * NCOMP + t] = b[(size_t)r0 * NCOMP + t];
-    xo += nloc;
-  }
-  packed_sweep<NCOMP, LW, PF>(s0, s1, meta, val, xs, lane);  // y = L^{-1} b
-  for (int p = 0, xo = 0; p < bpw; ++p) {                    // y *= D^{-1}
-    const int blk = wave_blk[w * bpw + p];
-    if (blk < 0) continue;
-    const int r0 = bptr[blk], nloc = bptr[blk + 1] - r0;
-    for (int t = lane; t < nloc; t += 64) {
-      const double d = dinv[r0 + t];
-#pragma unroll
-      for (int c = 0; c < NCOMP; ++c) xs[(xo + t) * NCOMP + c] *= d;
-    }
-    xo += nloc;
-  }
-  packed_sweep<NCOMP, LW, PF>(s1, s2, meta, val, xs, lane);  // x = U^{-1} y
-  double dot = 0.0;  // b . x over this wave's rows (CG's g.h right after the preconditioner, Prec.hpp:388 / SolverCG)
-  for (int p = 0, xo = 0; p < bpw; ++p) {
-    const int blk = wave_blk[w * bpw + p];
-    if (blk < 0) continue;
-    const int r0 = bptr[blk], nloc = bptr[blk + 1] - r0;
-    for (int t = lane; t < nloc * NCOMP; t += 64) {
-      const double v = xs[xo * NCOMP + t];
-      if (dot_partial) dot += b[(size_t)r0 * NCOMP + t] * v;
-      x[(size_t)r0 * NCOMP + t] = v;
-    }
-    xo += nloc;
-  }
-  if (dot_partial) {
-    dot = lane_group_sum<64>(dot);
-    if (lane == 0) dot_partial[w] = dot;
-  }
 }
 
 // ---- lane-owner stream: device side in nsx_ilu_lanes.hpp (shared with tools/ilu_lanes_bench.hip), schedule in host/ilu_stream.hpp
@@ -1171,17 +1005,6 @@ static void launch_lanes(nsx_handle *h, const IluSchedule &s, const double *b, d
 #undef NSX_GO
 }
 
-template <int NCOMP, int LW>
-static void launch_packed(nsx_handle *h, const IluSchedule &s, const double *b, double *x, double *dot_partial) {
-  const size_t shm = (size_t)s.max_wave_rows * NCOMP * sizeof(double);
-  static const int pf = getenv("NSX_PF") ? atoi(getenv("NSX_PF")) : 8;
-#define NSX_GO(PF_)                                                                                                               \
-  hipLaunchKernelGGL((k_ilu_solve_packed<NCOMP, LW, PF_>), dim3(s.n_waves), dim3(64), shm, h->stream, s.blocks_per_wave, s.pk_wave_blk.p, \
-                     s.block_ptr.p, s.pk_slab_ptr.p, s.pk_meta.p, s.pk_val.p, s.pk_dinv.p, b, x, dot_partial)
-  if (pf == 4) NSX_GO(4); else if (pf == 16) NSX_GO(16); else NSX_GO(8);
-#undef NSX_GO
-}
-
 template <int NCOMP>
 static void launch_ilu_solve(nsx_handle *h, const DevCsr &g, const IluSchedule &s, const double *lu, const double *b, double *x) {
   const size_t shm = (size_t)s.max_rows * NCOMP * sizeof(double);
@@ -1204,7 +1027,7 @@ bool ilu_solve(nsx_handle *h, const DevCsr &g, const IluSchedule &s, const doubl
     else ilu_solve_levelled<3>(h, g, s, lu, b, x);
     return false;
   }
-  const bool packed = s.packed_ok && (!s.stream || s.stream_ncomp == ncomp) && (size_t)(s.max_wave_rows + 64) * ncomp * sizeof(double) <= 64 * 1024;
+  const bool packed = s.packed_ok && s.stream_ncomp == ncomp;  // (the schedule already checked that a wave's rows fit 64 KiB of LDS)
   if (s.dense && ncomp == 1 && (size_t)s.max_rows * sizeof(double) <= 48 * 1024) {
     LaunchScope ls(h, name, 8.0 * (double)s.dn_entries + 16.0 * g.n_rows());
     const bool with_dot = dot_slot >= 0 && !h->comm && s.n_blocks >= 2 && s.n_blocks <= 512;  // a communicator needs equal counts on all ranks
@@ -1217,29 +1040,12 @@ bool ilu_solve(nsx_handle *h, const DevCsr &g, const IluSchedule &s, const doubl
   // has to read -- the IN-BLOCK entries of the factor (diagonal included; couplings between ranks are dropped by Ifpack's
   // local filter and are never touched) + right-hand side and solution.  The packed stream itself moves 768 B per slab.
   LaunchScope ls(h, name, 12.0 * (double)s.in_block_nnz + (double)g.n_rows() * (4 + 16.0 * ncomp));
-  if (packed && s.stream) {
+  if (packed) {
     const bool with_dot = dot_slot >= 0 && !h->comm && s.n_waves >= 2 && s.n_waves <= 512;  // one partial sum per wave
     double *dp = with_dot ? red_out(h, dot_slot, s.n_waves) : nullptr;
     if (ncomp == 1) launch_lanes<1>(h, s, b, x, dp);
     else if (ncomp == 2) launch_lanes<2>(h, s, b, x, dp);
     else launch_lanes<3>(h, s, b, x, dp);
-    if (with_dot) after_reduction(h, dot_slot, s.n_waves);
-    return with_dot;
-  }
-  if (packed) {
-    const int lw = s.lanes_per_row;
-    const bool with_dot = dot_slot >= 0 && !h->comm && s.n_waves >= 2 && s.n_waves <= 512;  // one partial sum per wave
-    double *dp = with_dot ? red_out(h, dot_slot, s.n_waves) : nullptr;
-#define NSX_PK(NC)                                                    \
-    if (lw == 8) launch_packed<NC, 8>(h, s, b, x, dp);                \
-    else if (lw == 16) launch_packed<NC, 16>(h, s, b, x, dp);         \
-    else if (lw == 32) launch_packed<NC, 32>(h, s, b, x, dp);         \
-    else if (lw == 64) launch_packed<NC, 64>(h, s, b, x, dp);         \
-    else NSX_THROW(NSX_ERR_ARG, "internal: lanes per row %d", lw);
-    if (ncomp == 1) { NSX_PK(1) }
-    else if (ncomp == 2) { NSX_PK(2) }
-    else { NSX_PK(3) }
-#undef NSX_PK
     if (with_dot) after_reduction(h, dot_slot, s.n_waves);
     return with_dot;
   }

@@ -41,7 +41,7 @@ def test_host_library_exports_every_declared_symbol():
 def test_kernels_are_compiled_for_gfx950(libnsx):
     from navierstokes_project_nm4pde_amd._lib import DEV_SO
     blob = open(DEV_SO, "rb").read()
-    assert b"gfx950" in blob and b"k_ilu_solve_packed" in blob and b"k_cell_convection" in blob
+    assert b"gfx950" in blob and b"k_ilu_solve_lanes" in blob and b"k_cell_convection" in blob
 
 
 def test_no_cpu_fallback_without_a_gpu(libnsx):
