@@ -1,10 +1,17 @@
 // nsx_dealii_adaptor.hpp — the reference-side binding of libnsx.
 //
-// NOT COMPILED IN THIS REPOSITORY: it needs deal.II >= 9.3.1 with Trilinos and MPI, none of which exist in the build
-// image; nothing here fakes their headers.  It is written against the public deal.II 9.3-9.5 API and the
-// C-ABI of include/nsx.h, to be dropped into the reference as Navier-Stokes/include/nsx_dealii_adaptor.hpp and linked with
-// -lnsx.  tests/test_adaptor_header.py checks what can be checked without deal.II: that every nsx_* call below exists in
-// include/nsx.h with the argument count used here.
+// NEVER BUILT OR RUN AGAINST deal.II IN THIS REPOSITORY (UNVERIFIED): it needs deal.II >= 9.3.1 with Trilinos and MPI, none of
+// which exist in the build image.  It is written against the public deal.II 9.3-9.5 API and the C-ABI of
+// include/nsx.h, to be dropped into the reference as Navier-Stokes/include/nsx_dealii_adaptor.hpp and linked with -lnsx.
+// tests/test_adaptor_header.py checks what can be checked without deal.II: that every nsx_* call below exists in include/nsx.h
+// with the argument count used here, and that the header and its usage block are valid C++ whose use of the third-party types
+// is consistent with the DECLARATION-ONLY interfaces of tests/stubs/ (g++ -fsyntax-only; written from memory of the public
+// deal.II / Epetra / MPI headers, so a misremembered deal.II signature is not caught).
+//
+// Numbering the library relies on (checked by nsx_set_mesh, which fails with NSX_ERR_ARG otherwise): velocity dofs first and
+// dof = dim * node + c for the dim components of a P2 node, pressure dofs after them — what DoFRenumbering::component_wise by
+// block gives on FESystem(FE_SimplexP(2)^dim, FE_SimplexP(1)) (NavierStokes3D.cpp:62-69).  A DoFHandler renumbered otherwise
+// (e.g. Cuthill-McKee across components) is rejected, not silently misread.
 //
 // What it replaces in lelecaruso/NavierStokes_Project_NM4PDE (file:line of the reference):
 //   NavierStokes::assemble(time)            Navier-Stokes/include/NavierStokes3D.hpp:126-127, src/NavierStokes3D.cpp:163-356
@@ -20,6 +27,8 @@
 //
 //   // NavierStokes3D.hpp, private:            nsx::Binding<dim> nsx_;
 //   // end of NavierStokes::setup() (:157):    nsx_.setup(dof_handler, *fe, *quadrature, nu, deltat, block_owned_dofs, MPI_COMM_WORLD);
+//   // NavierStokes::solve(), right after the initial interpolation `VectorTools::interpolate(dof_handler, u_0, solution_owned);
+//   //   solution = solution_owned;` (:696-697):   nsx_.write_solution(solution_owned);    // the device starts from u_0, not from zero
 //   void NavierStokes::assemble(const double &time) {            // :163-356
 //     nsx_.assemble(NSX_TEMAM);                                   // Temam term in the first step (:255)
 //     nsx_.apply_boundary_values(boundary_values_at(time));       // the std::map built exactly as at :327-352

@@ -723,6 +723,8 @@ static void mgs_chain(nsx_handle *h, Span sp, double *w, int dim, double *const 
 constexpr int LS_C = 8;       // basis vectors per pass of the dot kernel
 constexpr int LS_VALS = 64;   // r_j at j, Gram row at 32 + i, |w|^2 before the sweep at 63
 constexpr int LS_BLOCKS = 2048;  // most workgroups of the dot kernel (partial sums per value)
+constexpr int N_TMP_MAX = 32;
+enum { S_LS_NORM = 7 };          // scalar slot of the explicit |w|^2 of the distributed sweep (free in nsx_solve.hip's table)
 
 __global__ __launch_bounds__(256) void k_ls_dots(int n, int split, int gap, const double *__restrict__ w, MgsArgs V, int dim, double *__restrict__ partial) {
   __shared__ double sh[4][2 * LS_C + 1];
@@ -761,7 +763,7 @@ __global__ __launch_bounds__(256) void k_ls_dots(int n, int split, int gap, cons
       if (q < LS_C) {
         if (j < dim) partial[(size_t)j * LS_BLOCKS + blockIdx.x] = tot;
       } else if (q < 2 * LS_C) {
-        if (j < dim - 1) partial[(size_t)(32 + j) * LS_BLOCKS + blockIdx.x] = tot;
+        if (j < dim) partial[(size_t)(32 + j) * LS_BLOCKS + blockIdx.x] = tot;  // j = dim - 1: the diagonal |v_{dim-1}|^2
       } else if (c0 == 0) {
         partial[(size_t)63 * LS_BLOCKS + blockIdx.x] = tot;
       }
@@ -773,20 +775,25 @@ __global__ __launch_bounds__(256) void k_ls_dots(int n, int split, int gap, cons
 __global__ __launch_bounds__(256) void k_ls_finalize(int dim, int nblk, const double *__restrict__ partial, double *__restrict__ vals) {
   __shared__ double sh[4];
   const int v = blockIdx.x;
-  const bool used = v < dim || (v >= 32 && v < 32 + dim - 1) || v == 63;
+  const bool used = v < dim || (v >= 32 && v < 32 + dim) || v == 63;
   double a = 0.0;
   if (used)
     for (int q = threadIdx.x; q < nblk; q += 256) a += partial[(size_t)v * LS_BLOCKS + q];
   const double t = gx_block_sum(a, sh);
   if (threadIdx.x == 0) vals[v] = t;
 }
-// every rank, from the same all-reduced numbers: the new Gram row, then h = (I + L)^-1 r by forward substitution
-__global__ __launch_bounds__(64) void k_ls_solve(int dim, int consider, const double *__restrict__ vals, double *__restrict__ gram, double *__restrict__ scal_out) {
+// every rank, from the same all-reduced numbers: the new Gram row (diagonal included), then h = (I + L)^-1 r by forward
+// substitution, and |w|^2 AFTER the sweep without touching the vectors again:
+//     |w - sum_j h_j v_j|^2 = |w|^2 - 2 sum_j h_j r_j + sum_ij h_i G_ij h_j        (G = full Gram matrix of the basis, r_j = v_j . w)
+// -- exact algebra, no orthogonality assumed; in floating point a difference of numbers of size |w|^2, so its relative error is
+// eps |w|^2 / |w_after|^2: the host takes it when the sweep left more than 1 % of the norm and otherwise pays the second collective
+// (scal_out[dim] = |w_after|^2 by the formula, scal_out[dim + 1] = |w|^2 before the sweep).
+__global__ __launch_bounds__(64) void k_ls_solve(int dim, const double *__restrict__ vals, double *__restrict__ gram, double *__restrict__ scal_out) {
   __shared__ double G[32][33], hc[32];
   const int t = threadIdx.x;
-  for (int i = t; i < dim - 1; i += 64) gram[(dim - 1) * 32 + i] = vals[32 + i];
+  for (int i = t; i < dim; i += 64) gram[(dim - 1) * 32 + i] = vals[32 + i];
   __syncthreads();
-  for (int q = t; q < dim * 32; q += 64) G[q >> 5][q & 31] = (q & 31) < (q >> 5) ? gram[q] : 0.0;
+  for (int q = t; q < dim * 32; q += 64) G[q >> 5][q & 31] = (q & 31) <= (q >> 5) ? gram[q] : 0.0;
   __syncthreads();
   if (t == 0) {
     for (int j = 0; j < dim; ++j) {
@@ -795,7 +802,15 @@ __global__ __launch_bounds__(64) void k_ls_solve(int dim, int consider, const do
       hc[j] = s;
       scal_out[j] = s;
     }
-    if (consider) scal_out[dim + 1] = vals[63];
+    double cross = 0.0, quad = 0.0;
+    for (int j = 0; j < dim; ++j) {
+      cross += hc[j] * vals[j];
+      double row = 0.5 * G[j][j] * hc[j];
+      for (int i = 0; i < j; ++i) row += G[j][i] * hc[i];
+      quad += hc[j] * row;  // half of the symmetric form
+    }
+    scal_out[dim] = vals[63] - 2.0 * cross + 2.0 * quad;
+    scal_out[dim + 1] = vals[63];
   }
 }
 // w += (-h_j) v_j, j ascending; partial sums of |w|^2
@@ -830,16 +845,25 @@ static void mgs_lowsync(nsx_handle *h, Span sp, double *w, int dim, double *cons
     hipLaunchKernelGGL(k_ls_dots, dim3(nblk), dim3(256), 0, h->stream, n, sp.split, sp.gap, w, V, dim, h->ls_partial.p);
     hipLaunchKernelGGL(k_ls_finalize, dim3(LS_VALS), dim3(256), 0, h->stream, dim, nblk, h->ls_partial.p, h->ls_vals.p);
   }
-  comm_allreduce_partials(h, h->ls_vals.p, LS_VALS);  // collective 1: every r_j, the Gram row and |w|^2 before the sweep
-  hipLaunchKernelGGL(k_ls_solve, dim3(1), dim3(64), 0, h->stream, dim, consider ? 1 : 0, h->ls_vals.p, gram, h->scal.p + slot0);
+  comm_allreduce_partials(h, h->ls_vals.p, LS_VALS);  // THE collective of the sweep: every r_j, the Gram row and |w|^2 before the sweep
+  hipLaunchKernelGGL(k_ls_solve, dim3(1), dim3(64), 0, h->stream, dim, h->ls_vals.p, gram, h->scal.p + slot0);
   for (int i = 0; i <= dim + 1; ++i) h->slot_nb[slot0 + i] = 0;
+  const int nb = red_blocks(h, n);
   {
     LaunchScope ls(h, "mgs_update", 8.0 * n * (dim + 2));
-    const int nb = red_blocks(h, n);
-    hipLaunchKernelGGL(k_ls_update, dim3(nb), dim3(256), 0, h->stream, n, sp.split, sp.gap, w, V, dim, h->scal.p + slot0, red_out(h, slot0 + dim, nb));
-    after_reduction(h, slot0 + dim, nb);  // collective 2: |w|^2
+    // the update also leaves the partial sums of |w|^2 (slot S_LS_NORM), in case the formula cannot be trusted
+    hipLaunchKernelGGL(k_ls_update, dim3(nb), dim3(256), 0, h->stream, n, sp.split, sp.gap, w, V, dim, h->scal.p + slot0, red_out(h, S_LS_NORM, nb));
   }
-  read_scalars(h, slot0, dim + 1 + (consider ? 1 : 0), out);
+  double tmp[N_TMP_MAX + 2];
+  read_scalars(h, slot0, dim + 2, tmp);
+  // one collective: |w_after|^2 from the Gram algebra, unless the sweep removed more than 99 % of the norm (cancellation)
+  const bool by_formula = h->ls_mode >= 2 && tmp[dim] > 1e-4 * tmp[dim + 1];
+  if (!by_formula) {
+    after_reduction(h, S_LS_NORM, nb);  // collective 2: |w|^2 summed over the vector
+    tmp[dim] = read_scalar(h, S_LS_NORM);
+  }
+  for (int i = 0; i <= dim; ++i) out[i] = tmp[i];
+  if (consider) out[dim + 1] = tmp[dim + 1];
 }
 
 // out[0..dim) = h(i), out[dim] = |w|^2 after the sweep.  Returns true when w was also normalised (only if asked to).
@@ -859,7 +883,7 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
   if (h->comm || h->mgs_max_wg == 0 || dim + 2 > MGS_STEPS || per_thread > 20) {
     // distributed solve: two collectives per sweep (mgs_lowsync); NSX_MGS_LOWSYNC=0: one launch + all-reduce per link, as the
     // reference's MPI run does.  Without a Gram cache (or too many vectors for it) the chain as well.
-    if (h->ls_mode < 0) h->ls_mode = !(getenv("NSX_MGS_LOWSYNC") && atoi(getenv("NSX_MGS_LOWSYNC")) == 0);  // read once per handle
+    if (h->ls_mode < 0) h->ls_mode = getenv("NSX_MGS_LOWSYNC") ? atoi(getenv("NSX_MGS_LOWSYNC")) : 2;  // read once per handle: 0 chain, 1 two collectives, 2 one
     // (one GPU, vector too long for the persistent sweep: the same two passes read the basis twice instead of four times)
     const bool too_long = !h->comm && !h->mgs_disabled && per_thread > 20;
     if ((h->comm || too_long) && h->ls_mode && gram && dim <= 31) mgs_lowsync(h, sp, w, dim, vs, slot0, out, consider, gram);

@@ -14,7 +14,7 @@ def main():
     import torch.distributed as dist
     from navierstokes_project_nm4pde_amd import nsx
     from navierstokes_project_nm4pde_amd.frontend import DoFs, Mesh, Tables
-    from navierstokes_project_nm4pde_amd.problem import InletVelocity, cylinder_boundary_values
+    from navierstokes_project_nm4pde_amd.problem import InletVelocity, cylinder_boundary_values, obstacle_faces
     dim, level, n_sub, prec = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
     out_path = sys.argv[5]
     ordering = sys.argv[6] if len(sys.argv) > 6 else "first_touch"
@@ -31,6 +31,11 @@ def main():
     rng = np.random.default_rng(5)
     u0 = 0.05 * rng.standard_normal(dofs.n_dofs)
     dev.set_solution(u0)
+    # compute_forces over the ranks: every rank integrates the obstacle faces of the cells it owns, the two sums are all-reduced
+    # (Utilities::MPI::sum, reference NavierStokes3D.cpp:830-831)
+    from navierstokes_project_nm4pde_amd.frontend import Tables as _T
+    dev.set_force_faces(*obstacle_faces(mesh), _T(dim, _T.FACE))
+    forces = []
     res = {"iters": [], "vmult": None}
     t = 0.0
     sols = []
@@ -51,8 +56,9 @@ def main():
         st = dev.solve_time_step(prec, tol_abs=1e-11, inner_rtol=1e-10)
         res["iters"].append(st["outer_iterations"])
         sols.append(dev.gather_solution())
+        forces.append(dev.compute_forces())
     if rank == 0:
-        np.savez(out_path, sols=np.array(sols), vmult=vm, x=x, u0=u0, iters=np.array(res["iters"]))
+        np.savez(out_path, sols=np.array(sols), vmult=vm, x=x, u0=u0, iters=np.array(res["iters"]), forces=np.array(forces))
     dev.close()
     dist.destroy_process_group()
 

@@ -54,9 +54,10 @@ def test_adaptor_calls_match_the_c_abi():
     assert needed <= {n for n, _ in used}, needed - {n for n, _ in used}
 
 
-def test_adaptor_cites_the_members_it_replaces_and_says_it_is_not_compiled_here():
+def test_adaptor_cites_the_members_it_replaces_and_says_it_is_unverified():
     raw = open(os.path.join(ROOT, "include", "nsx_dealii_adaptor.hpp")).read()
-    assert "NOT COMPILED IN THIS REPOSITORY" in raw
+    assert "NEVER BUILT OR RUN AGAINST deal.II IN THIS REPOSITORY (UNVERIFIED)" in raw
+    assert "write_solution(solution_owned)" in raw.split("#ifndef NSX_DEALII_ADAPTOR_HPP")[0]   # the usage block hands u_0 to the device (:696-697)
     for cite in ("NavierStokes3D.hpp:126-127", "NavierStokes3D.cpp:163-356", "NavierStokes3D.cpp:361-544", "NavierStokes3D.cpp:546-640",
                  "Preconditioners.hpp:122-126", "336-340", "431-435"):
         assert cite in raw, cite
@@ -67,3 +68,18 @@ def test_adaptor_cites_the_members_it_replaces_and_says_it_is_not_compiled_here(
     if os.path.isdir(ref):
         for rel in ("include/NavierStokes3D.hpp", "src/NavierStokes3D.cpp", "include/Preconditioners.hpp"):
             assert os.path.exists(os.path.join(ref, rel))
+
+
+def test_adaptor_compiles_against_the_declared_interfaces():
+    """g++ -fsyntax-only of the adaptor + its usage block against tests/stubs (declaration-only deal.II / Epetra / MPI interfaces):
+    valid C++, every template instantiated, nsx_* calls type-checked against include/nsx.h.  NOT a check of deal.II's real API."""
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    if gxx is None:
+        import pytest
+        pytest.skip("no g++")
+    r = subprocess.run([gxx, "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "tests", "stubs"),
+                        "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "stubs", "adaptor_check.cpp")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-4000:]

@@ -1,5 +1,6 @@
-"""GPU suite at BASELINE.json's full single-GPU size (~1.09 M DoF, configs[1]): the oracle cannot finish there in
-seconds, so parity is checked through size-independent properties of the operators and of the solve."""
+"""GPU suite at BASELINE.json's full single-GPU size (~1.09 M DoF, configs[1], the bench layout: 4096 ranks, 512 Schur blocks,
+colour order): size-independent properties of the operators and of the solve, and -- since the OpenMP build of the oracle does
+a whole step of this mesh in seconds -- the stages of one time step against the oracle entry by entry."""
 import numpy as np
 import pytest
 
@@ -106,3 +107,81 @@ def test_full_size_ilu_factors_and_triangular_solves(big):
         w = L @ ((U @ v) / dinv[:, None])
         z = dev.ilu_apply(which, w.ravel())
         assert np.abs(z.reshape(n, ncomp) - v).max() < 1e-9 * np.abs(v).max()
+
+
+def test_full_size_bench_layout_against_the_oracle(big):
+    """configs[1] oracle-checked, not property-checked: assemble (first step) + assemble_time_step + Dirichlet rows, the block
+    mat-vec, the Schur product, both ILU(0) factorisations and one Yosida vmult at tight inner tolerance, device against
+    oracle/liboracle_mt.so (the oracle's source on all host cores) from identical state on the bench layout itself
+    (reference NavierStokes3D.cpp:163-544, Preconditioners.hpp:336-408)."""
+    import oracle
+    from navierstokes_project_nm4pde_amd import nsx
+    from navierstokes_project_nm4pde_amd.frontend import Tables
+    from navierstokes_project_nm4pde_amd.problem import InletVelocity, cylinder_boundary_values
+    from conftest import rel_err
+    mesh, d, dev = big
+    dt, H = 2e-4, 0.41
+    ora = oracle.Oracle(d, Tables(3), 1e-3, dt, threads=max(2, oracle.usable_cores()))
+    ora.set_schur_blocks(d.owned_p_ptr[::8])
+    X = d.support_points
+
+    def state(seed, amp):
+        rng = np.random.default_rng(seed)
+        u = np.zeros(d.n_dofs)
+        prof = 16 * 9.0 * X[0:d.n_u:3, 1] * X[0:d.n_u:3, 2] * (H - X[0:d.n_u:3, 1]) * (H - X[0:d.n_u:3, 2]) / H ** 4
+        u[0:d.n_u:3] = amp * prof * (1 + 0.1 * np.sin(7 * X[0:d.n_u:3, 0])) + 1e-3 * rng.standard_normal(d.n_u // 3)
+        u[1:d.n_u:3] = 0.05 * amp * prof * np.cos(5 * X[1:d.n_u:3, 0]) + 1e-3 * rng.standard_normal(d.n_u // 3)
+        u[2:d.n_u:3] = 1e-3 * rng.standard_normal(d.n_u // 3)
+        u[d.n_u:] = 0.1 * rng.standard_normal(d.n_p)
+        return u
+
+    def both(fn):
+        fn(dev)
+        fn(ora)
+
+    def put(u):
+        dev.set_solution(u)
+        ora.solution[:] = u
+        ora.solution_owned[:] = u
+
+    # the reference's padded (0,0) graph against the scalar P2 graph: same-component entries carry the scalar operator
+    g0 = ora.graphs[0]
+    rows = np.repeat(np.arange(len(g0[0]) - 1), np.diff(g0[0]))
+    sel = (rows % 3 == 0) & (g0[1] % 3 == 0)
+    put(state(1234, 1.0))
+    both(lambda o: o.assemble(nsx.TEMAM))                                # NavierStokes::assemble (first step)
+    put(state(99, 0.8))
+    both(lambda o: o.assemble_time_step(0))                              # NavierStokes::assemble_time_step
+    bd, bv = cylinder_boundary_values(d, InletVelocity(3), 2 * dt)
+    both(lambda o: o.apply_boundary_values(bd, bv))
+    dev.prec_initialize(0)                                                # (also gives the scalar graph below)
+    rp, ci, lu = dev.ilu(0)
+    nnz_row = np.zeros(d.n_u, dtype=np.int64)
+    nnz_row[0::3] = np.diff(rp)
+    rpd = np.concatenate([[0], np.cumsum(nnz_row)]).astype(np.int32)
+    graph = (rpd, (3 * ci).astype(np.int32))
+    assert sel.sum() == len(ci)
+    for which, name in ((0, "system"), (2, "convection"), (1, "mass")):
+        assert rel_err(dev.export_block(which, 0, graph=graph), ora.matrix(which, 0)[sel]) < 1e-12, name
+    assert np.abs(ora.matrix(0, 0)[~sel & (rows % 3 != g0[1] % 3)]).max() == 0.0   # no cross-component entry in the reference layout
+    for block in (1, 2):
+        assert rel_err(dev.export_block(0, block), ora.matrix(0, block)) < 1e-12
+    assert rel_err(dev.rhs, ora.rhs) < 1e-12
+    assert rel_err(dev.solution, ora.solution) < 1e-14                    # Dirichlet values written into the ghosted solution
+    x = np.random.default_rng(7).standard_normal(d.n_dofs)
+    assert rel_err(dev.system_vmult(x), ora.system_vmult(x)) < 1e-12
+    # Yosida initialize: S = B D^-1 B^T on the product pattern, ILU(0) of F and of S per rank / Schur block
+    ora.prec_initialize(0)
+    S_o, S_d = ora.schur(), dev.schur()
+    assert (S_o.indptr == S_d.indptr).all() and (S_o.indices == S_d.indices).all()
+    assert rel_err(S_d.data, S_o.data) < 1e-12
+    assert rel_err(lu, ora.ilu_F()[sel]) < 1e-10
+    assert rel_err(dev.ilu(1)[2], ora.ilu_S(S_o.nnz)) < 1e-10
+    # one application of the preconditioner with the inner solves converged to 1e-10
+    src = np.random.default_rng(11).standard_normal(d.n_dofs)
+    yd, sd = dev.prec_vmult(0, src, inner_rtol=1e-10)
+    yo, so = ora.prec_vmult(0, src, inner_rtol=1e-10)
+    assert sd["status"] == 0 and so["status"] == 0
+    assert rel_err(yd, yo) < 1e-8
+    for key in ("inner_F_iterations", "inner_S_iterations"):
+        assert abs(sd[key] - so[key]) <= max(2, 0.05 * so[key]), key
