@@ -86,11 +86,19 @@ def transfer_state(src_dofs, x, dst_dofs):
     return out
 
 
-def schur_block_table(dofs, schur_blocks, rank=0, world=1):
-    """coarser ILU blocks for the Schur matrix: unions of consecutive virtual ranks (of this GPU)"""
+SCHUR_ROWS = 96  # default size limit of the Schur ILU blocks (rows): blocks of at most 96 rows keep their explicit inverses in registers
+
+
+def schur_block_table(dofs, schur_blocks, rank=0, world=1, max_rows=SCHUR_ROWS):
+    """coarser ILU blocks for the Schur matrix: unions of consecutive virtual ranks (of this GPU).  schur_blocks = 0: as many
+    consecutive ranks per block as fit `max_rows` pressure rows (blocks of 86 - 96 rows at 4096 ranks: ~505 blocks of equal
+    size instead of 512 blocks of 55 - 173 rows); schur_blocks > 0: that many blocks of equal rank count (round 1 / 2 layout)."""
     import numpy as np
+    from navierstokes_project_nm4pde_amd.frontend import merge_ranks
     n_sub = dofs.n_subdomains // world
     mine = dofs.owned_p_ptr[rank * n_sub:(rank + 1) * n_sub + 1]
+    if not schur_blocks:
+        return merge_ranks(mine, max_rows)
     stride = max(1, n_sub // max(1, schur_blocks // world))
     ptr = list(mine[::stride])
     if ptr[-1] != mine[-1]:
@@ -108,7 +116,7 @@ def gpu_run(dofs, tables, steps, warmup, schur_blocks, device, profile_steps=5, 
     # the N > 1 control flow be rehearsed with several ranks on ONE card
     dev = nsx.Nsx(dofs, tables, NU, DT, device=device, rank=rank, world=world, comm=os.environ.get("NSX_BENCH_COMM", "rccl"))
     try:
-        if schur_blocks and schur_blocks < dofs.n_subdomains:
+        if schur_blocks < dofs.n_subdomains:
             dev.set_schur_blocks(schur_block_table(dofs, schur_blocks, rank, world))
         inlet = InletVelocity(3)  # test case 2, u_m = 9 (reference NavierStokes3D.hpp:37,80)
         dev.set_solution(np.zeros(dofs.n_dofs))  # u_0 = 0 (reference NavierStokes3D.hpp:200)
@@ -304,7 +312,8 @@ def main():
     ap.add_argument("--level", type=int, default=None, help="mesh level (default: 7 ~ 1.09M DoF per GPU)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak", help="which figure becomes `value` for N > 1 (both are reported)")
     ap.add_argument("--ranks", type=int, default=4096, help="virtual MPI ranks = ILU(0) blocks of F")
-    ap.add_argument("--schur-blocks", type=int, default=512, help="ILU(0) blocks of the Schur matrix")
+    ap.add_argument("--schur-blocks", type=int, default=0,
+                    help="ILU(0) blocks of the Schur matrix; 0 (default): consecutive ranks merged up to %d pressure rows per block" % SCHUR_ROWS)
     ap.add_argument("--ordering", choices=("colour", "first_touch", "colour_all"), default="colour",
                     help="velocity node order inside a virtual rank (include/nsx_host.h: nsxh_distribute_dofs_ordered)")
     ap.add_argument("--balance", choices=("cells", "owned"), default="cells",
@@ -419,10 +428,11 @@ def main():
         "time_steps_per_s_of_this_mesh": raw,
         "dtype": "f64", "data": "synthetic (block-structured tetrahedral cylinder mesh, u0 = 0, reference inlet profile)",
         "config": {"workload": "3D flow-past-cylinder, P2/P1 (reference FE_SimplexP), %d DoF, %d cells, dt=2e-4, nu=1e-3, u_m=9, "
-                               "GMRES(1e-4 abs)+Yosida(inner 1e-2), ILU(0) per rank with %d ranks (bisection balanced on %s; Schur: %d blocks), "
+                               "GMRES(1e-4 abs)+Yosida(inner 1e-2), ILU(0) per rank with %d ranks (bisection balanced on %s; Schur: %s), "
                                "%s node order inside a rank"
                                % (dofs.n_dofs, dofs.n_cells, args.ranks * world, "owned nodes" if args.balance == "owned" else "cells",
-                                  args.schur_blocks * world, args.ordering),
+                                  ("%d blocks" % (args.schur_blocks * world)) if args.schur_blocks else ("consecutive ranks merged up to %d rows per block" % SCHUR_ROWS),
+                                  args.ordering),
                    "n_dofs": dofs.n_dofs, "n_cells": dofs.n_cells,
                    "parallelism": ("1 GPU, no communication" if world == 1 else
                                    "mesh partitioned over %d GPUs: %s" % (world, "RCCL ghost exchange (grouped ncclSend/ncclRecv) + ncclAllReduce of the dot products"

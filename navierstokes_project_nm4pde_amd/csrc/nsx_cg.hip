@@ -23,6 +23,7 @@ namespace nsx {
 constexpr int CG_THREADS = 256;  // 256 or 512 (two halves of 256: each streams the slabs of every other 16-row round of the block)
 constexpr int CG_NW = CG_THREADS / 64, CG_NG = CG_THREADS / 16;  // waves, 16-lane row groups
 constexpr int CG_MAXB = 256;    // rows of one Schur block: one thread per row in the update phases
+constexpr int CG_PRES_ROWS = 128;  // up to this many rows per block the explicit inverses can stay in registers (k_cg_schur<6>: 96 rows, <8>: 128)
 constexpr int CG_MAX_WG = 1024;
 constexpr int CG_NV = 3;        // values per exchange
 constexpr int CG_RING = 4;      // mailbox rows in flight; row (e + 2) % 4 is emptied at exchange e
@@ -182,6 +183,7 @@ __device__ __forceinline__ void cg_block_spmv(int s0, int s1, const double *__re
 }
 #undef NSX_CG_LOAD
 
+template <int RPG>  // 0: the block inverses are streamed in every iteration; 6 / 8: blocks of at most 96 / 128 rows, inverses in registers
 __global__ __launch_bounds__(CG_THREADS) void k_cg_schur(const int32_t *__restrict__ bptr, const int32_t *__restrict__ u_ptr,
                                                   const int32_t *__restrict__ u_cols, const int32_t *__restrict__ s_ptr,
                                                   const double *__restrict__ sval, const uint16_t *__restrict__ slidx,
@@ -226,14 +228,46 @@ __global__ __launch_bounds__(CG_THREADS) void k_cg_schur(const int32_t *__restri
       pv[c] = (live && j < nb) ? prow[j] : 0.0;
     }
   };
+  // RPG > 0: every block has at most 16 * RPG rows and its explicit inverse P_b stays in REGISTERS for the whole solve (row group
+  // g holds rows g, g + 16, ...: RPG rows x RPG values per lane, 72 VGPRs at 96 rows), loaded once; the iteration then streams the
+  // operator slabs only.  P_b and negative_S_tilde change once per time step at most, a solve runs ~20 iterations and a step ~25
+  // solves: re-reading the 34 MB of inverses in every iteration was half of the kernel's traffic.
+  constexpr bool PRES = RPG > 0;
+  double pr[PRES ? RPG : 1][PRES ? RPG : 1];
+  if constexpr (PRES) {
+#pragma unroll
+    for (int r = 0; r < RPG; ++r) {
+      const int q = grp + CG_NG * r;
+      const double *prow = Pb + (size_t)(q < nb ? q : 0) * nb;
+#pragma unroll
+      for (int c = 0; c < RPG; ++c) {
+        const int j = lane + 16 * c;
+        pr[r][c] = (q < nb && j < nb) ? prow[j] : 0.0;
+      }
+    }
+  }
   auto prefetch_P = [&]() {
-    if (nb <= 128) {
-      fetch(grp, pa);
-      fetch(grp + CG_NG, pb);
+    if constexpr (!PRES) {
+      if (nb <= 128) {
+        fetch(grp, pa);
+        fetch(grp + CG_NG, pb);
+      }
     }
   };
   auto apply_P = [&]() {  // prefetch_P() has been called
-    if (nb <= 128) {
+    if constexpr (PRES) {
+#pragma unroll
+      for (int r = 0; r < RPG; ++r) {
+        const int q = grp + CG_NG * r;
+        if (q < nb) {
+          double acc = 0.0;
+#pragma unroll
+          for (int c = 0; c < RPG; ++c) acc += pr[r][c] * gs[lane + 16 * c];
+          acc = cg_group_sum<16>(acc);
+          if (lane == 0) hs[q] = acc;
+        }
+      }
+    } else if (nb <= 128) {
       auto use = [&](int q, const double(&pv)[8]) {
         if (q >= nb) return;
         double acc = 0.0;
@@ -449,12 +483,19 @@ static void cg_setup(nsx_handle *h) {
   }
   int cus = 0, per_cu = 0;
   HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->prm.device));
-  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_schur, CG_THREADS, 0));
+  int per_cu_res[2] = {0, 0};
+  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_schur<0>, CG_THREADS, 0));
+  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_res[0], k_cg_schur<6>, CG_THREADS, 0));
+  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_res[1], k_cg_schur<8>, CG_THREADS, 0));
+  h->cg_max_wg_res[0] = std::min(CG_MAX_WG, per_cu_res[0] * cus);
+  h->cg_max_wg_res[1] = std::min(CG_MAX_WG, per_cu_res[1] * cus);
   h->cg_box.alloc(2 * CG_REGION + 2);
   HIP_CHECK(hipMemsetAsync(h->cg_box.p, 0xff, 2 * CG_REGION * sizeof(unsigned long long), h->stream));
   HIP_CHECK(hipMemsetAsync(h->cg_box.p + 2 * CG_REGION, 0, 2 * sizeof(unsigned long long), h->stream));
   h->cg_max_wg = std::min(CG_MAX_WG, per_cu * cus);
-  if (getenv("NSX_DEBUG")) fprintf(stderr, "[nsx] persistent Schur CG: %d CUs x %d resident workgroups, grid <= %d\n", cus, per_cu, h->cg_max_wg);
+  if (getenv("NSX_DEBUG"))
+    fprintf(stderr, "[nsx] persistent Schur CG: %d CUs x %d resident workgroups, grid <= %d (block inverses in registers: <= 96 rows x %d, <= 128 rows x %d)\n", cus, per_cu,
+            h->cg_max_wg, per_cu_res[0], per_cu_res[1]);
 }
 
 // CG on negative_S_tilde with the explicit block inverses as preconditioner, one launch.  Returns false when the launch-per-
@@ -465,6 +506,10 @@ bool cg_schur_persistent(nsx_handle *h, double *x, const double *b, double rtol,
   if (h->comm || !s.dense || s.max_rows > CG_MAXB || !pl.ok || !pl.values_current) return false;
   cg_setup(h);
   if (h->cg_max_wg == 0 || s.n_blocks > h->cg_max_wg) return false;
+  static const bool pres_ok = !(getenv("NSX_CG_PRES") && atoi(getenv("NSX_CG_PRES")) == 0);
+  // rows per group of the register-resident variant: the smallest that holds the largest block, if its grid is resident
+  const int rpg = !pres_ok ? 0 : (s.max_rows <= 96 && s.n_blocks <= h->cg_max_wg_res[0]) ? 6 : (s.max_rows <= 128 && s.n_blocks <= h->cg_max_wg_res[1]) ? 8 : 0;
+  const bool pres = rpg > 0;
   const int n = h->n_p;
   if ((int)h->cg_vec.n < 3 * n) h->cg_vec.alloc((size_t)3 * n);
   double *D0 = h->cg_vec.p, *D1 = D0 + n, *H = D1 + n;
@@ -477,9 +522,13 @@ bool cg_schur_persistent(nsx_handle *h, double *x, const double *b, double rtol,
   {
     LaunchScope ls(h, "cg_S", 0.0);
     pe = ls.e;
-    hipLaunchKernelGGL(k_cg_schur, dim3(s.n_blocks), dim3(CG_THREADS), 0, h->stream, s.block_ptr.p, pl.u_ptr.p, pl.u_cols.p, pl.s_ptr.p, pl.s_val.p,
-                       pl.s_lidx.p, pl.s_info.p, s.dn_off.p, s.dn_P.p, b, x, D0, D1, H, rtol, maxiter, box, box_other, pub_vals, pub_flag, seq,
-                       err_dev, h->gx_drop_wg);
+#define NSX_CG_GO(PRES_)                                                                                                                              \
+  hipLaunchKernelGGL(k_cg_schur<PRES_>, dim3(s.n_blocks), dim3(CG_THREADS), 0, h->stream, s.block_ptr.p, pl.u_ptr.p, pl.u_cols.p, pl.s_ptr.p, pl.s_val.p, \
+                     pl.s_lidx.p, pl.s_info.p, s.dn_off.p, s.dn_P.p, b, x, D0, D1, H, rtol, maxiter, box, box_other, pub_vals, pub_flag, seq, err_dev,    \
+                     h->gx_drop_wg)
+    if (rpg == 6) NSX_CG_GO(6); else if (rpg == 8) NSX_CG_GO(8); else NSX_CG_GO(0);
+#undef NSX_CG_GO
+    h->cg_resident = pres;
   }
   h->cg_parity ^= 1;
   wait_published(h, seq);
@@ -500,7 +549,8 @@ bool cg_schur_persistent(nsx_handle *h, double *x, const double *b, double rtol,
   *last = h->pub_host[S_CGP + 1];
   *status = st;
   // algorithmic bytes: per iteration the matrix (12 B / entry) and the block inverses once, plus the vectors
-  if (pe) pe->bytes += (double)(*steps + 1) * (10.0 * h->gS.nnz() + 8.0 * (double)s.dn_entries + 48.0 * n);
+  // (block inverses resident in registers: read once per solve)
+  if (pe) pe->bytes += (double)(*steps + 1) * (10.0 * h->gS.nnz() + 48.0 * n) + (pres ? 1.0 : (double)(*steps + 1)) * 8.0 * (double)s.dn_entries;
   return true;
 }
 

@@ -279,7 +279,8 @@ struct nsx_handle {
   nsx::DevBuf<unsigned long long> cg_box;
   nsx::CgPlan cgplan;
   nsx::DevBuf<double> cg_vec;
-  int cg_parity = 0, cg_max_wg = 0;
+  int cg_parity = 0, cg_max_wg = 0, cg_max_wg_res[2] = {0, 0};  // _res: resident-grid limits of the variants that keep the block inverses in registers (96 / 128 rows)
+  bool cg_resident = false;                            // the last Schur CG ran with the block inverses in registers
   bool cg_disabled = false;
   // ---- force evaluation (compute_forces): obstacle faces + face-quadrature tables
   int ff_n = 0, ff_nq = 0;

@@ -309,3 +309,16 @@ def ilu_stream_apply(rowptr, colind, block_ptr, lu, b, ncomp=1, blocks_per_wave=
     if rc:
         raise ValueError("nsxh_ilu_stream_apply failed (%d)" % rc)
     return x
+
+
+def merge_ranks(ptr, max_rows):
+    """Coarser ILU blocks as unions of CONSECUTIVE ranks: ranks are added to a block while it stays within `max_rows` rows
+    (a rank larger than that stays a block of its own).  ptr: [n_ranks + 1] node ranges; returns the block table."""
+    ptr = np.asarray(ptr)
+    out = [int(ptr[0])]
+    for k in range(1, len(ptr)):
+        if ptr[k] - out[-1] > max_rows and ptr[k - 1] > out[-1]:
+            out.append(int(ptr[k - 1]))
+    if out[-1] != ptr[-1]:
+        out.append(int(ptr[-1]))
+    return np.array(out, dtype=np.int32)

@@ -10,11 +10,11 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def big():
     from navierstokes_project_nm4pde_amd import nsx
-    from navierstokes_project_nm4pde_amd.frontend import DoFs, Mesh, Tables
+    from navierstokes_project_nm4pde_amd.frontend import DoFs, Mesh, Tables, merge_ranks
     mesh = Mesh.cylinder(3, 7).partition(1, 4096)
     dofs, tables = DoFs(mesh, "colour"), Tables(3)          # the bench configuration
     dev = nsx.Nsx(dofs, tables, 1e-3, 2e-4)
-    dev.set_schur_blocks(dofs.owned_p_ptr[::8])             # 512 Schur blocks, as in bench.py
+    dev.set_schur_blocks(merge_ranks(dofs.owned_p_ptr, 96))  # ~505 Schur blocks of at most 96 rows, as in bench.py
     yield mesh, dofs, dev
     dev.close()
 
@@ -75,10 +75,11 @@ def test_full_size_ilu_factors_and_triangular_solves(big):
     (b) ILU^{-1} (L D U v) = v for the velocity blocks (packed sparse sweeps, pair-of-groups rows, 3 interleaved
         components) and for the Schur blocks (explicit block inverses)."""
     import scipy.sparse as sp
+    from navierstokes_project_nm4pde_amd.frontend import merge_ranks
     mesh, d, dev = big
     rng = np.random.default_rng(7)
     dev.prec_initialize(0)                                   # factors of the system assembled by the previous test
-    for which, ptr, ncomp in ((0, d.owned_u_ptr, 3), (1, d.owned_p_ptr[::8], 1)):
+    for which, ptr, ncomp in ((0, d.owned_u_ptr, 3), (1, merge_ranks(d.owned_p_ptr, 96), 1)):
         rp, ci, lu = dev.ilu(which)
         n = len(rp) - 1
         rows = np.repeat(np.arange(n), np.diff(rp))
@@ -116,13 +117,13 @@ def test_full_size_bench_layout_against_the_oracle(big):
     (reference NavierStokes3D.cpp:163-544, Preconditioners.hpp:336-408)."""
     import oracle
     from navierstokes_project_nm4pde_amd import nsx
-    from navierstokes_project_nm4pde_amd.frontend import Tables
+    from navierstokes_project_nm4pde_amd.frontend import Tables, merge_ranks
     from navierstokes_project_nm4pde_amd.problem import InletVelocity, cylinder_boundary_values
     from conftest import rel_err
     mesh, d, dev = big
     dt, H = 2e-4, 0.41
     ora = oracle.Oracle(d, Tables(3), 1e-3, dt, threads=max(2, oracle.usable_cores()))
-    ora.set_schur_blocks(d.owned_p_ptr[::8])
+    ora.set_schur_blocks(merge_ranks(d.owned_p_ptr, 96))
     X = d.support_points
 
     def state(seed, amp):

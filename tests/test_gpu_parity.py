@@ -117,8 +117,12 @@ def test_time_steps_tight_tolerance(pair, prec):
         dev.apply_boundary_values(bd, bv)
         ora.apply_boundary_values(bd, bv)
         assert rel_err(dev.export_block(0, 0), ora.matrix(0, 0)) < 1e-8
-        sd = dev.solve_time_step(prec, tol_abs=1e-11, inner_rtol=1e-10)
-        so = ora.solve_time_step(prec, tol_abs=1e-11, inner_rtol=1e-10)
+        # the absolute tolerance has to stay above the floor the inner solves (1e-10 relative) leave in the preconditioned
+        # residual, which scales with the right-hand side ~ 1 / deltat: at deltat = 1e-3 (|rhs| = 7) a run at 1e-11 sits ON that
+        # floor and converges at iteration 19 or only after the restart, by rounding (measured: device 19, oracle 32)
+        tol = 1e-10 if p.deltat == 1e-3 else 1e-11
+        sd = dev.solve_time_step(prec, tol_abs=tol, inner_rtol=1e-10)
+        so = ora.solve_time_step(prec, tol_abs=tol, inner_rtol=1e-10)
         assert sd["status"] == 0 and so["status"] == 0
         scale = np.abs(ora.solution_owned).max()
         assert np.abs(dev.solution_owned - ora.solution_owned).max() / scale < 1e-8

@@ -15,7 +15,7 @@ mesh, dofs, tables = bench.build_problem(level, 4096, 1, "colour")
 inlet = InletVelocity(3)
 os.environ["NSX_CG_PERSISTENT"] = "0"
 dev = nsx.Nsx(dofs, tables, 1e-3, 2e-4)  # a developed state to start both variants from
-dev.set_schur_blocks(bench.schur_block_table(dofs, 512))
+dev.set_schur_blocks(bench.schur_block_table(dofs, 0))
 dev.set_solution(np.zeros(dofs.n_dofs))
 t = 0.0
 for step in range(3):
@@ -29,7 +29,7 @@ res = {}
 for flag in ("0", "1"):
     os.environ["NSX_CG_PERSISTENT"] = flag
     dev = nsx.Nsx(dofs, tables, 1e-3, 2e-4)
-    dev.set_schur_blocks(bench.schur_block_table(dofs, 512))
+    dev.set_schur_blocks(bench.schur_block_table(dofs, 0))
     dev.set_solution(state)
     dev.assemble(nsx.TEMAM)
     dev.apply_boundary_values(*cylinder_boundary_values(dofs, inlet, t + 2e-4))

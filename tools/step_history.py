@@ -12,7 +12,7 @@ from navierstokes_project_nm4pde_amd.problem import InletVelocity, cylinder_boun
 n_steps = int(sys.argv[1]) if len(sys.argv) > 1 else 45
 mesh, dofs, tables = bench.build_problem(7, 4096, 1, "colour", balance=os.environ.get("NSX_BALANCE", "cells"))
 dev = nsx.Nsx(dofs, tables, 1e-3, 2e-4)
-dev.set_schur_blocks(bench.schur_block_table(dofs, 512))
+dev.set_schur_blocks(bench.schur_block_table(dofs, 0))
 inlet = InletVelocity(3)
 dev.set_solution(np.zeros(dofs.n_dofs))
 t = 0.0
