@@ -37,12 +37,12 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 BASE_LEVEL, BASE_DOFS = 7, 1089643  # the N = 1 workload: level-7 cylinder mesh
-PMC_PROFILE = "profiles/r02_pmc_fetch_write_per_kernel.json"
+PMC_PROFILE = "profiles/r03_pmc_fetch_write_per_kernel.json"
 LAYOUT_PROFILE = "profiles/r02_layout_iterations.json"
 NU, DT = 1e-3, 2e-4
 
 # scope name used by the library's HIP-event timer -> kernel symbol in rocprofv3 output
-KERNEL_OF = {"mgs_sweep": "void nsx::k_mgs_blk<8, 2, true>", "add_and_dot": "void nsx::k_reduce<1>", "dot": "void nsx::k_reduce<0>", "spmv_F": "void nsx::k_spmv_blocked<3, 16>",
+KERNEL_OF = {"mgs_sweep": "void nsx::k_mgs_one<8, 10>", "add_and_dot": "void nsx::k_reduce<1>", "dot": "void nsx::k_reduce<0>", "spmv_F": "void nsx::k_spmv_blocked<3, 16>",
              "ilu_solve_F": "void nsx::k_ilu_solve_lanes<3, 2, 8>", "ilu_solve_S": "nsx::k_ilu_apply_dense",
              "axpby": "nsx::k_axpby", "spmv_S": "void nsx::k_spmv_csr<32>", "cg_S": "nsx::k_cg_schur"}
 
@@ -52,7 +52,7 @@ def pmc_traffic(scope):
     WRITE_SIZE in separate passes, values in KiB; gfx950 FETCH_SIZE counts 64 B per 128-B request, so it is doubled:
     /opt/skills/guides/MI355X_MICROARCH.md section HBM).  A constant read from a profile, not measured in this run (PMC
     counters need rocprofv3 around the process); None when no profile is committed for the kernel."""
-    for rel in (PMC_PROFILE, "profiles/r01_pmc_fetch_write_per_kernel.json"):
+    for rel in (PMC_PROFILE, "profiles/r02_pmc_fetch_write_per_kernel.json"):
         try:
             with open(os.path.join(ROOT, rel)) as f:
                 tab = json.load(f)

@@ -629,12 +629,255 @@ __global__ __launch_bounds__(256) void k_mgs_blk(int n, int split, int gap, doub
   MGS_STAMP();
 }
 
+// ---- the whole sweep in ONE grid-wide exchange ---------------------------------------------------------------------------
+// The linearity that k_mgs_blk uses for M links of the chain holds for all of them:  h_j = r_j - sum_{i<j} G_ji h_i  with
+// r_j = v_j . w (the vector as it ENTERS the sweep) and G the Gram matrix of the basis (no orthogonality assumed).  G is kept
+// on the device per GMRES nesting level: the sweep that meets v_{dim-1} for the first time computes its row g_i = v_{dim-1} . v_i
+// beside the r_j (the same registers), all older rows were computed by the earlier sweeps of the cycle.  So ONE exchange carries
+// r_0..r_{dim-1}, g_0..g_{dim-1} and |w|^2; every workgroup then solves the same unit-lower-triangular system from the same
+// totals, applies  w += (-h_j) v_j  for j ascending (the chain's operations on every entry, in the chain's order) from the
+// basis vectors it still holds in registers, and gets |w|^2 AFTER the sweep without another exchange from
+//     |w - sum_j h_j v_j|^2 = |w|^2 - 2 h.r + h^T G h
+// (a difference of numbers of size |w|^2: taken when the sweep leaves more than 1 % of the norm, i.e. its rounding error stays
+// below 1e-12 |w'|^2; otherwise a second exchange sums |w'|^2 itself).  A sweep of `dim` links costs one exchange (two when
+// the formula is refused) instead of dim / 2 + 1, and every basis vector is still read exactly once as long as the thread can
+// keep the block (dim <= DMAX); beyond, the oldest dim - DMAX vectors are streamed twice (dots, then update).
+// The exchange is two hops like the others: value v is summed over the workgroups' mailboxes by workgroup v % nwg (the 2 dim + 1
+// sums are spread over the grid instead of queueing in workgroup 0), the totals are picked up by everybody.
+// Mailboxes: box[v * nwg + wg], totals behind them at box[MGS_ONE_VALS * MGS_MAX_WG + v].
+constexpr int MGS_ONE_VALS = 2 * (MGS_STEPS - 2) + 2;  // r_j, g_j (j < 30), |w|^2 before, |w|^2 after (second exchange)
+static_assert((size_t)MGS_ONE_VALS * MGS_MAX_WG + MGS_ONE_VALS <= MGS_BLK_REGION, "the one-exchange sweep shares the mailbox regions of k_mgs_blk");
+
+template <int E, int DMAX>
+__global__ __launch_bounds__(256) void k_mgs_one(int n, int split, int gap, double *__restrict__ w, MgsArgs V, int dim, double *__restrict__ gram,
+                                                 unsigned long long *box, unsigned long long *box_next, int reset_words, double *__restrict__ scal_out,
+                                                 int *err_host, unsigned long long *tail, int normalize, int consider, double *pub_vals,
+                                                 unsigned long long *pub_flag, unsigned long long seq, int drop_wg) {
+  __shared__ double sh[4][MGS_ONE_VALS];   // per-wave sums of every value
+  __shared__ double tot[MGS_ONE_VALS];     // grid totals
+  __shared__ double G[MGS_STEPS][MGS_STEPS + 1], hc[MGS_STEPS];
+  __shared__ double s_norm2;
+  __shared__ int s_err;
+  const int nwg = gridDim.x, wg = blockIdx.x, T = nwg * 256, t = wg * 256 + threadIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (threadIdx.x == 0) s_err = 0;
+  unsigned long long *total = box + (size_t)MGS_ONE_VALS * MGS_MAX_WG, *total_next = box_next + (size_t)MGS_ONE_VALS * MGS_MAX_WG;
+  for (int q = t; q < reset_words; q += T) box_next[q] = GX_EMPTY;
+  if (wg == 0 && threadIdx.x < MGS_ONE_VALS) total_next[threadIdx.x] = GX_EMPTY;
+  const int nvals = 2 * dim + 1;  // r_j at j, g_j at dim + j, |w|^2 at 2 dim
+  double wv[E], vb[DMAX][E];
+  int idx[E];
+#pragma unroll
+  for (int k = 0; k < E; ++k) {
+    const int i0 = t + k * T;
+    idx[k] = i0 < n ? i0 + (i0 >= split ? gap : 0) : -1;
+    wv[k] = idx[k] >= 0 ? w[idx[k]] : 0.0;
+  }
+  // the block the thread keeps: the LAST min(dim, DMAX) basis vectors (the newest one, whose Gram row is due, is among them)
+  const int j_keep = dim > DMAX ? dim - DMAX : 0;
+#pragma unroll
+  for (int i = 0; i < DMAX; ++i) {
+    const double *__restrict__ vp = j_keep + i < dim ? V.v[j_keep + i] : nullptr;
+#pragma unroll
+    for (int k = 0; k < E; ++k) vb[i][k] = (vp && idx[k] >= 0) ? ld_stream<1>(vp + idx[k]) : 0.0;
+  }
+  // v_{dim-1} in registers of its own (static index): the second operand of the Gram row
+  double vl[E];
+#pragma unroll
+  for (int k = 0; k < E; ++k) vl[k] = 0.0;
+#pragma unroll
+  for (int i = 0; i < DMAX; ++i)
+    if (j_keep + i == dim - 1) {
+#pragma unroll
+      for (int k = 0; k < E; ++k) vl[k] = vb[i][k];
+    }
+  auto wave_post = [&](int v, double a) {  // this wave's sum of value v
+    const double s_ = gx_wave_sum(a);
+    if (lane == 0) sh[wave][v] = s_;
+  };
+  {
+    double a = 0.0;
+#pragma unroll
+    for (int k = 0; k < E; ++k) a += wv[k] * wv[k];
+    wave_post(2 * dim, a);
+  }
+  for (int j = 0; j < j_keep; ++j) {  // older vectors: streamed, not kept (dim > DMAX only)
+    const double *__restrict__ vp = V.v[j];
+    double ar = 0.0, ag = 0.0;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+      const double x_ = idx[k] >= 0 ? ld_stream<1>(vp + idx[k]) : 0.0;
+      ar += wv[k] * x_;
+      ag += vl[k] * x_;
+    }
+    wave_post(j, ar);
+    wave_post(dim + j, ag);
+  }
+#pragma unroll
+  for (int i = 0; i < DMAX; ++i)
+    if (j_keep + i < dim) {
+      double ar = 0.0, ag = 0.0;
+#pragma unroll
+      for (int k = 0; k < E; ++k) {
+        ar += wv[k] * vb[i][k];
+        ag += vl[k] * vb[i][k];
+      }
+      wave_post(j_keep + i, ar);
+      wave_post(dim + j_keep + i, ag);
+    }
+  __syncthreads();
+  // ---- hop 1: mailboxes; value v is summed by workgroup v % nwg
+  int lerr = 0;
+  for (int v = threadIdx.x; v < nvals; v += 256)
+    if (wg != drop_wg) gx_post(box + (size_t)v * nwg + wg, (sh[0][v] + sh[1][v]) + (sh[2][v] + sh[3][v]));  // drop_wg: fault injection, see k_mgs
+  for (int v = wg; v < nvals; v += nwg) {
+    double a = 0.0;
+    for (int q = threadIdx.x; q < nwg; q += 256) a += gx_wait_value(box + (size_t)v * nwg + q, &lerr);
+    if (lerr) s_err = 1;
+    __syncthreads();  // sh is reused by the block sum below (and s_err must be seen)
+    const double s_ = gx_wave_sum(a);
+    if (lane == 0) sh[wave][0] = s_;
+    __syncthreads();
+    if (threadIdx.x == 0 && !s_err) gx_post(total + v, (sh[0][0] + sh[1][0]) + (sh[2][0] + sh[3][0]));  // a total built on a timed-out mailbox never goes out
+    __syncthreads();
+  }
+  // ---- hop 2: everybody picks up the totals
+  for (int v = threadIdx.x; v < nvals; v += 256) {
+    tot[v] = gx_wait_value(total + v, &lerr);
+    if (lerr) s_err = 1;
+  }
+  __syncthreads();
+  bool dead = s_err != 0;
+  if (!dead) {
+    // Gram matrix of the basis: older rows from memory, the new row from this exchange; then h by forward substitution and the
+    // norm after the sweep, one wave, lane j = link j
+    for (int q = threadIdx.x; q < (dim - 1) * MGS_STEPS; q += 256) {
+      const int r_ = q / MGS_STEPS, c_ = q % MGS_STEPS;
+      if (c_ <= r_) G[r_][c_] = gram[r_ * 32 + c_];
+    }
+    if ((int)threadIdx.x < dim) G[dim - 1][threadIdx.x] = tot[dim + threadIdx.x];
+    __syncthreads();
+    if (wave == 0) {
+      double hj = 0.0;
+      for (int j = 0; j < dim; ++j) {
+        // s = sum_{i<j} G_ji h_i over the lanes i < j
+        double part = (lane < j) ? G[j][lane] * hj : 0.0;
+        part = gx_wave_sum(part);
+        if (lane == j) hj = tot[j] - part;
+      }
+      if (lane < dim) hc[lane] = hj;
+      // |w'|^2 = |w|^2 - 2 h.r + h^T G h   (G symmetric: row lane against all columns)
+      double quad = 0.0;
+      if (lane < dim) {
+        double row = 0.0;
+        for (int i = 0; i < dim; ++i) row += (i <= lane ? G[lane][i] : G[i][lane]) * __shfl(hj, i, 64);
+        quad = hj * (row - 2.0 * tot[lane]);
+      } else {
+        for (int i = 0; i < dim; ++i) (void)__shfl(hj, i, 64);
+      }
+      quad = gx_wave_sum(quad);
+      if (lane == 0) s_norm2 = tot[2 * dim] + quad;
+    }
+    __syncthreads();
+    // w += (-h_j) v_j, j ascending: the streamed (older) vectors first, then the kept block
+    for (int j = 0; j < j_keep; ++j) {
+      const double *__restrict__ vp = V.v[j];
+      const double alpha = -1.0 * hc[j];
+#pragma unroll
+      for (int k = 0; k < E; ++k)
+        if (idx[k] >= 0) wv[k] += alpha * ld_stream<1>(vp + idx[k]);
+    }
+#pragma unroll
+    for (int i = 0; i < DMAX; ++i)
+      if (j_keep + i < dim) {
+        const double alpha = -1.0 * hc[j_keep + i];
+#pragma unroll
+        for (int k = 0; k < E; ++k) wv[k] += alpha * vb[i][k];
+      }
+    // the formula is a difference of numbers of size |w|^2: refuse it when less than 1 % of the norm is left
+    double norm2 = s_norm2;
+    const double w2 = tot[2 * dim];
+    if (!(norm2 > 1e-4 * w2)) {  // uniform over the grid (same totals everywhere): a second exchange sums |w'|^2 itself
+      double a = 0.0;
+#pragma unroll
+      for (int k = 0; k < E; ++k) a += wv[k] * wv[k];
+      const double s_ = gx_wave_sum(a);
+      __syncthreads();
+      if (lane == 0) sh[wave][0] = s_;
+      __syncthreads();
+      const int v = 2 * dim + 1;
+      if (threadIdx.x == 0 && wg != drop_wg) gx_post(box + (size_t)v * nwg + wg, (sh[0][0] + sh[1][0]) + (sh[2][0] + sh[3][0]));
+      if (wg == v % nwg) {
+        double b = 0.0;
+        for (int q = threadIdx.x; q < nwg; q += 256) b += gx_wait_value(box + (size_t)v * nwg + q, &lerr);
+        if (lerr) s_err = 1;
+        __syncthreads();
+        const double sb = gx_wave_sum(b);
+        if (lane == 0) sh[wave][1] = sb;
+        __syncthreads();
+        if (threadIdx.x == 0 && !s_err) gx_post(total + v, (sh[0][1] + sh[1][1]) + (sh[2][1] + sh[3][1]));
+      }
+      if (threadIdx.x == 0) {
+        const double x_ = gx_wait_value(total + v, &lerr);
+        if (lerr) s_err = 1;
+        s_norm2 = x_;
+      }
+      __syncthreads();
+      dead = s_err != 0;
+      norm2 = s_norm2;
+    }
+    if (!dead && normalize) {  // vv *= 1. / s with s = sqrt(|vv|^2), skipped for s == 0 (SolverGMRES)
+      const double nrm = sqrt(norm2);
+      const bool second_sweep = consider && !(nrm > 10. * sqrt(w2) * 1.4901161193847656e-08);
+      if (nrm != 0.0 && !second_sweep) {
+        const double inv = 1. / nrm;
+#pragma unroll
+        for (int k = 0; k < E; ++k) wv[k] = inv * wv[k];
+      }
+    }
+  }
+  if (dead) {
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(err_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (wg == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(pub_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    return;
+  }
+  if (wg == 0) {
+    // the new Gram row for the later sweeps of this cycle, the coefficients for the device and the host
+    if ((int)threadIdx.x < dim) {
+      gram[(dim - 1) * 32 + threadIdx.x] = tot[dim + threadIdx.x];
+      scal_out[threadIdx.x] = hc[threadIdx.x];
+      __hip_atomic_store(pub_vals + threadIdx.x, hc[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (threadIdx.x == 0) {
+      scal_out[dim] = s_norm2;
+      scal_out[dim + 1] = tot[2 * dim];
+      __hip_atomic_store(pub_vals + dim, s_norm2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(pub_vals + dim + 1, tot[2 * dim], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(pub_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (threadIdx.x == 0) tail[wg] = seq;  // this workgroup commits its part of w
+#pragma unroll
+  for (int k = 0; k < E; ++k)
+    if (idx[k] >= 0) w[idx[k]] = wv[k];
+}
+
+static const void *mgs_one_fn(int e) { return e <= 8 ? (const void *)k_mgs_one<8, 10> : (const void *)k_mgs_one<10, 8>; }
+
 template <int M>
 static const void *mgs_blk_fn(int e) {
   return e <= 8 ? (const void *)k_mgs_blk<8, M, true> : e <= 10 ? (const void *)k_mgs_blk<10, M, true> : (const void *)k_mgs_blk<20, M, false>;
 }
 static const void *mgs_fn(int m, int e) {
   switch (m) {
+    case 0: return mgs_one_fn(e);
     case 2: return mgs_blk_fn<2>(e);
     case 3: return mgs_blk_fn<3>(e);
     case 4: return mgs_blk_fn<4>(e);
@@ -650,8 +893,8 @@ static void mgs_setup(nsx_handle *h) {
     h->mgs_disabled = true;
     return;
   }
-  // links per exchange: 1 = deal.II's chain link by link (k_mgs), 2..5 = k_mgs_blk
-  h->mgs_links = getenv("NSX_MGS_LINKS") ? std::max(1, std::min(5, atoi(getenv("NSX_MGS_LINKS")))) : 2;
+  // links per exchange: 0 = all of them (k_mgs_one, the default), 1 = deal.II's chain link by link (k_mgs), 2..5 = k_mgs_blk
+  h->mgs_links = getenv("NSX_MGS_LINKS") ? std::max(0, std::min(5, atoi(getenv("NSX_MGS_LINKS")))) : 0;
   int cus = 0;
   HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->prm.device));
   const size_t region = std::max(MGS_REGION, MGS_BLK_REGION);
@@ -873,19 +1116,21 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
   if (!h->comm) mgs_setup(h);
   // entries per thread: the smallest instantiation (8, 10, 20) whose resident grid covers the vector
   int nwg = 1, per_thread = 1 << 30, e_inst = 0;
-  for (int k = 0; k < 3 && h->mgs_max_wg; ++k) {
+  const int n_inst = h->mgs_links == 0 ? 2 : 3;  // the one-exchange sweep keeps a block of basis vectors in registers: 8 or 10 entries per thread
+  for (int k = 0; k < n_inst && h->mgs_max_wg; ++k) {
     static const int es[3] = {8, 10, 20};
     nwg = std::max(1, std::min(h->mgs_max_wg_e[k], cdiv(n, 256 * 4)));
     per_thread = cdiv(n, (int64_t)nwg * 256);
     e_inst = es[k];
     if (per_thread <= es[k]) break;
   }
-  if (h->comm || h->mgs_max_wg == 0 || dim + 2 > MGS_STEPS || per_thread > 20) {
+  const int per_thread_max = h->mgs_links == 0 ? 10 : 20;
+  if (h->comm || h->mgs_max_wg == 0 || dim + 2 > MGS_STEPS || per_thread > per_thread_max || (h->mgs_links == 0 && !gram)) {
     // distributed solve: two collectives per sweep (mgs_lowsync); NSX_MGS_LOWSYNC=0: one launch + all-reduce per link, as the
     // reference's MPI run does.  Without a Gram cache (or too many vectors for it) the chain as well.
     if (h->ls_mode < 0) h->ls_mode = getenv("NSX_MGS_LOWSYNC") ? atoi(getenv("NSX_MGS_LOWSYNC")) : 2;  // read once per handle: 0 chain, 1 two collectives, 2 one
     // (one GPU, vector too long for the persistent sweep: the same two passes read the basis twice instead of four times)
-    const bool too_long = !h->comm && !h->mgs_disabled && per_thread > 20;
+    const bool too_long = !h->comm && !h->mgs_disabled && per_thread > per_thread_max;
     if ((h->comm || too_long) && h->ls_mode && gram && dim <= 31) mgs_lowsync(h, sp, w, dim, vs, slot0, out, consider, gram);
     else mgs_chain(h, sp, w, dim, vs, slot0, out, consider);
     return false;
@@ -913,7 +1158,15 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
     // sweep safe is the bounded wait: should a workgroup be missing (another stream or process holds compute units), the kernel
     // ends without writing w and the sweep is redone by the launch-per-link chain below.
     const void *fn = mgs_fn(M, e_inst);
-    if (M == 1) {
+    if (M == 0) {
+      // k_mgs_one: mailboxes box[v * nwg + wg] for the 2 dim + 1 values of the single exchange (+ 1 for the explicit norm)
+      int reset_words = reset_wg * reset_steps;
+      double *gram_ = gram;
+      void *args[] = {&n_, &split, &gap, &w, &V, &dim_, &gram_, &box, &box_next, &reset_words, &sout, &err, &tail, &norm_, &consider_, &pub_vals, &pub_flag, &seq_, &drop_wg};
+      HIP_CHECK(hipLaunchKernel(fn, dim3(nwg), dim3(256), args, 0, h->stream));
+      h->mgs_used_wg[h->mgs_parity] = 1;
+      h->mgs_used_steps[h->mgs_parity] = (2 * dim + 2) * nwg;
+    } else if (M == 1) {
       void *args[] = {&n_, &split, &gap, &w, &V, &dim_, &box, &box_next, &reset_wg, &reset_steps, &sout, &err, &tail, &norm_, &consider_, &pub_vals, &pub_flag, &seq_, &drop_wg};
       HIP_CHECK(hipLaunchKernel(fn, dim3(nwg), dim3(256), args, 0, h->stream));
       h->mgs_used_wg[h->mgs_parity] = nwg;
@@ -945,7 +1198,7 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
     if (ran_ahead) h->mgs_redo_ahead = true;
     return false;
   }
-  for (int i = 0; i <= dim + (consider ? 1 : 0); ++i) out[i] = h->pub_host[slot0 + i];
+  for (int i = 0; i <= dim + ((consider || h->mgs_links == 0) ? 1 : 0); ++i) out[i] = h->pub_host[slot0 + i];
   if (!normalize) return false;
   // the kernel's own decision, recomputed from the same two numbers
   return !consider || std::sqrt(out[dim]) > 10. * std::sqrt(out[dim + 1]) * 1.4901161193847656e-08;

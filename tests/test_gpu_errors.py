@@ -113,14 +113,16 @@ def test_unsupported_quadrature_size_fails_loudly(prob):
 
 def test_gram_schmidt_as_one_launch_equals_the_launch_per_link_chain(prob):
     """NSX_MGS=0 runs SolverGMRES' add_and_dot chain as separate launches; NSX_MGS_LINKS=1 the same chain link by link in one
-    persistent launch (same arithmetic per entry); NSX_MGS_LINKS=m (default 2) evaluates m links per grid-wide exchange by
-    linearity of the dot product: h_j = v_j.w_j0 - sum_i (v_i.v_j) h_i, identical in exact arithmetic whatever the basis, so the
-    coefficients differ by the rounding of the sums only.  All must walk through the same history and end at the same vector."""
+    persistent launch (same arithmetic per entry); NSX_MGS_LINKS=m (2..5) evaluates m links per grid-wide exchange by linearity
+    of the dot product: h_j = v_j.w_j0 - sum_i (v_i.v_j) h_i, identical in exact arithmetic whatever the basis, so the
+    coefficients differ by the rounding of the sums only; NSX_MGS_LINKS=0 (the default) ALL links in one exchange with the basis'
+    Gram matrix kept on the device, and |w|^2 after the sweep from the same numbers.  All must walk through the same history and
+    end at the same vector."""
     res = []
     # NSX_MGS_MAXWG=1: a resident grid of one workgroup cannot hold the vector (> 20 entries per thread), which is what a mesh of
     # several million DoF does to the real grid: the sweep then runs as two passes (all dot products + the Gram row, then the updates)
-    cases = [{"NSX_MGS": "0"}, {"NSX_MGS_LINKS": "1"}, {"NSX_MGS_LINKS": "2"}, {"NSX_MGS_LINKS": "3"}, {"NSX_MGS_LINKS": "4"}, {"NSX_MGS_LINKS": "5"},
-             {"NSX_MGS_MAXWG": "1"}]
+    cases = [{"NSX_MGS": "0"}, {"NSX_MGS_LINKS": "0"}, {"NSX_MGS_LINKS": "1"}, {"NSX_MGS_LINKS": "2"}, {"NSX_MGS_LINKS": "3"}, {"NSX_MGS_LINKS": "4"},
+             {"NSX_MGS_LINKS": "5"}, {"NSX_MGS_MAXWG": "1"}]
     for env in cases:
         os.environ.update(env)
         try:
