@@ -652,7 +652,7 @@ template <int E, int DMAX>
 __global__ __launch_bounds__(256) void k_mgs_one(int n, int split, int gap, double *__restrict__ w, MgsArgs V, int dim, double *__restrict__ gram,
                                                  unsigned long long *box, unsigned long long *box_next, int reset_words, double *__restrict__ scal_out,
                                                  int *err_host, unsigned long long *tail, int normalize, int consider, double *pub_vals,
-                                                 unsigned long long *pub_flag, unsigned long long seq, int drop_wg) {
+                                                 unsigned long long *pub_flag, unsigned long long seq, int drop_wg, double norm_guard) {
   __shared__ double sh[4][MGS_ONE_VALS];   // per-wave sums of every value
   __shared__ double tot[MGS_ONE_VALS];     // grid totals
   __shared__ double G[MGS_STEPS][MGS_STEPS + 1], hc[MGS_STEPS];
@@ -797,7 +797,7 @@ __global__ __launch_bounds__(256) void k_mgs_one(int n, int split, int gap, doub
     // the formula is a difference of numbers of size |w|^2: refuse it when less than 1 % of the norm is left
     double norm2 = s_norm2;
     const double w2 = tot[2 * dim];
-    if (!(norm2 > 1e-4 * w2)) {  // uniform over the grid (same totals everywhere): a second exchange sums |w'|^2 itself
+    if (!(norm2 > norm_guard * w2)) {  // uniform over the grid (same totals everywhere): a second exchange sums |w'|^2 itself
       double a = 0.0;
 #pragma unroll
       for (int k = 0; k < E; ++k) a += wv[k] * wv[k];
@@ -1074,6 +1074,14 @@ __global__ __launch_bounds__(256) void k_ls_update(int n, int split, int gap, do
   if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
 
+// |w'|^2 = |w|^2 - 2 h.r + h^T G h is a difference of numbers of size |w|^2: its relative error is about eps * dim * |w|^2 / |w'|^2.
+// It is accepted when |w'|^2 > guard * |w|^2 (default 1e-2: the norm of the new basis vector is then good to ~1e-13, two orders
+// below the tightest tolerance the parity tests solve to); otherwise |w'|^2 is summed over the vector (one more exchange / collective).
+static double mgs_norm_guard() {
+  static const double g = getenv("NSX_MGS_NORM_GUARD") ? atof(getenv("NSX_MGS_NORM_GUARD")) : 1e-2;
+  return g;
+}
+
 static void mgs_lowsync(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int slot0, double *out, bool consider, double *gram) {
   if (!h->ls_partial.p) {
     h->ls_partial.alloc((size_t)LS_VALS * LS_BLOCKS);
@@ -1100,7 +1108,7 @@ static void mgs_lowsync(nsx_handle *h, Span sp, double *w, int dim, double *cons
   double tmp[N_TMP_MAX + 2];
   read_scalars(h, slot0, dim + 2, tmp);
   // one collective: |w_after|^2 from the Gram algebra, unless the sweep removed more than 99 % of the norm (cancellation)
-  const bool by_formula = h->ls_mode >= 2 && tmp[dim] > 1e-4 * tmp[dim + 1];
+  const bool by_formula = h->ls_mode >= 2 && tmp[dim] > mgs_norm_guard() * tmp[dim + 1];
   if (!by_formula) {
     after_reduction(h, S_LS_NORM, nb);  // collective 2: |w|^2 summed over the vector
     tmp[dim] = read_scalar(h, S_LS_NORM);
@@ -1162,7 +1170,8 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
       // k_mgs_one: mailboxes box[v * nwg + wg] for the 2 dim + 1 values of the single exchange (+ 1 for the explicit norm)
       int reset_words = reset_wg * reset_steps;
       double *gram_ = gram;
-      void *args[] = {&n_, &split, &gap, &w, &V, &dim_, &gram_, &box, &box_next, &reset_words, &sout, &err, &tail, &norm_, &consider_, &pub_vals, &pub_flag, &seq_, &drop_wg};
+      double guard_ = mgs_norm_guard();
+      void *args[] = {&n_, &split, &gap, &w, &V, &dim_, &gram_, &box, &box_next, &reset_words, &sout, &err, &tail, &norm_, &consider_, &pub_vals, &pub_flag, &seq_, &drop_wg, &guard_};
       HIP_CHECK(hipLaunchKernel(fn, dim3(nwg), dim3(256), args, 0, h->stream));
       h->mgs_used_wg[h->mgs_parity] = 1;
       h->mgs_used_steps[h->mgs_parity] = (2 * dim + 2) * nwg;

@@ -47,7 +47,7 @@ def test_distributed_solve_equals_single_process(tmp_path, dim, level, world, n_
         if step == 0:
             y = dev.system_vmult(d["x"])
             assert np.abs(y - d["vmult"]).max() < 1e-12 * np.abs(y).max()
-        st = dev.solve_time_step(prec, tol_abs=1e-11, inner_rtol=1e-10)
+        st = dev.solve_time_step(prec, tol_abs=1e-10, inner_rtol=1e-10)  # 1e-11 sits on the floor the inner solves leave: 18 or 30 iterations by rounding
         x = dev.solution_owned
         assert np.abs(x - d["sols"][step]).max() < 1e-8 * np.abs(x).max(), step
         assert abs(st["outer_iterations"] - int(d["iters"][step])) <= 1
