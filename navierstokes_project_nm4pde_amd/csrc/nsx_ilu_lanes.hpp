@@ -80,14 +80,32 @@ __device__ __forceinline__ void lane_tick(const LaneSlot<E> &s, const LaneSlot<E
   __builtin_amdgcn_wave_barrier();  // compiler only: the next tick's reads stay behind this write
 }
 
-// sa .. sb: the slabs of one sweep of this wave, a multiple of ILU_STREAM_ALIGN = 8 (host/ilu_stream.hpp pads with idle slabs)
+// sa .. sb: the slabs of one sweep of this wave, a multiple of ILU_STREAM_ALIGN = 8 (host/ilu_stream.hpp pads with idle slabs).
+// The stream is padded behind its end (ILU_STREAM_PAD slabs): prefetching needs no bounds check.  Uniform base + 32-bit lane
+// offset: the loads take the scalar-base addressing form (no 64-bit vector address arithmetic per load).
+template <int E, int PF>
+__device__ __forceinline__ void lane_load(LaneSlot<E> (&S)[PF], int s0, const uint32_t *__restrict__ meta, const double *__restrict__ val, unsigned lane) {
+  constexpr int MW = (E + 2) / 2;
+  const double *vs_ = val + (size_t)s0 * (64 * E);
+  const uint32_t *ms_ = meta + (size_t)s0 * (64 * MW);
+#pragma unroll
+  for (int k = 0; k < PF; ++k) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) S[k].v[e] = lanes_ld(vs_ + ((k * 64u + lane) * E + e));
+#pragma unroll
+    for (int j = 0; j < MW; ++j) S[k].m[j] = lanes_ld(ms_ + ((k * 64u + lane) * MW + j));
+  }
+}
+
+// A: the first PF slabs of the sweep, already requested by the caller (lane_load(A, sa, ...)): a wave that is alone on its SIMD
+// has nothing else to hide that first trip to memory behind, so the kernel issues it in front of its load / scale passes
 template <int NCOMP, int E, int PF>
-__device__ __forceinline__ void lane_sweep(int sa, int sb, const uint32_t *__restrict__ meta, const double *__restrict__ val, unsigned lane,
-                                           uint32_t scratch) {
+__device__ __forceinline__ void lane_sweep(LaneSlot<E> (&A)[PF], int sa, int sb, const uint32_t *__restrict__ meta, const double *__restrict__ val,
+                                           unsigned lane, uint32_t scratch) {
   static_assert(PF == 4 || PF == 8, "sweeps are padded to multiples of 8 slabs; the two operand sets of the gathers alternate tick by tick");
   constexpr int MW = (E + 2) / 2;
   if (sa >= sb) return;
-  LaneSlot<E> A[PF], B[PF], idle;
+  LaneSlot<E> B[PF], idle;
   LaneOperands<NCOMP, E> o0, o1;
   double acc[NCOMP];
 #pragma unroll
@@ -96,17 +114,6 @@ __device__ __forceinline__ void lane_sweep(int sa, int sb, const uint32_t *__res
   for (int e = 0; e < E; ++e) idle.v[e] = 0.0;
 #pragma unroll
   for (int k = 0; k < MW; ++k) idle.m[k] = scratch | (scratch << 16);
-  // the stream is padded behind its end (ILU_STREAM_PAD slabs): prefetching needs no bounds check.  Uniform base + 32-bit lane
-  // offset: the loads take the scalar-base addressing form (no 64-bit vector address arithmetic per load).
-#define NSX_LOAD(S, S0)                                                \
-  {                                                                    \
-    const double *vs_ = val + (size_t)(S0) * (64 * E);                 \
-    const uint32_t *ms_ = meta + (size_t)(S0) * (64 * MW);             \
-    _Pragma("unroll") for (int k = 0; k < PF; ++k) {                   \
-      _Pragma("unroll") for (int e = 0; e < E; ++e) S[k].v[e] = lanes_ld(vs_ + ((k * 64u + lane) * E + e));   \
-      _Pragma("unroll") for (int j = 0; j < MW; ++j) S[k].m[j] = lanes_ld(ms_ + ((k * 64u + lane) * MW + j)); \
-    }                                                                  \
-  }
   // PF ticks; the last one pre-reads for the first tick of the next PF slabs (nothing of this wave behind the sweep's end)
 #define NSX_USE(S, SNEXT, S0)                                                                  \
   {                                                                                            \
@@ -116,16 +123,14 @@ __device__ __forceinline__ void lane_sweep(int sa, int sb, const uint32_t *__res
       lane_tick<NCOMP, E>(S[k + 1], k + 2 < PF ? S[k + 2 < PF ? k + 2 : 0] : (more_ ? SNEXT : idle), scratch, acc, o1, o0); \
     }                                                                                          \
   }
-  NSX_LOAD(A, sa)
   lane_read<NCOMP, E>(A[0], o0);
   for (int s0 = sa; s0 < sb; s0 += 2 * PF) {
-    NSX_LOAD(B, s0 + PF)
+    lane_load<E, PF>(B, s0 + PF, meta, val, lane);
     NSX_USE(A, B[0], s0)
     if (s0 + PF >= sb) break;
-    NSX_LOAD(A, s0 + 2 * PF)
+    lane_load<E, PF>(A, s0 + 2 * PF, meta, val, lane);
     NSX_USE(B, A[0], s0 + PF)
   }
-#undef NSX_LOAD
 #undef NSX_USE
 }
 

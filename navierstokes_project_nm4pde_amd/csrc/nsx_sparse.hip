@@ -895,7 +895,7 @@ __global__ __launch_bounds__(256) void k_ilu_solve(const int32_t *__restrict__ b
 }
 
 // ---- lane-owner stream: device side in nsx_ilu_lanes.hpp (shared with tools/ilu_lanes_bench.hip), schedule in host/ilu_stream.hpp
-constexpr int LANES_K = 8;  // rows per lane and memory trip in the load / scale / store loops of k_ilu_solve_lanes
+constexpr int LANES_K = 12;  // rows per lane and memory trip in the load / scale / store passes of k_ilu_solve_lanes (768 rows: one trip for a wave of 8 blocks)
 
 template <int NCOMP, int E, int PF>
 __global__ __launch_bounds__(64) void k_ilu_solve_lanes(const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ rows,
@@ -908,10 +908,36 @@ __global__ __launch_bounds__(64) void k_ilu_solve_lanes(const int32_t *__restric
   const unsigned lane = threadIdx.x;
   const int s0 = slab_ptr[2 * w], s1 = slab_ptr[2 * w + 1], s2 = slab_ptr[2 * w + 2];
   const int rb = row_ptr[w], nr = row_ptr[w + 1] - rb;
-  // Flat loops over the wave's rows (LDS order), LANES_K rows per lane at a time with all loads of a stage issued back to back:
-  // a stage is ONE trip to memory, not one per row (the wave is alone on its SIMD: nothing else hides the latency)
+  // The wave is alone on its SIMD: nothing hides a trip to memory but the wave's own other requests.  So everything whose address
+  // is known at once is requested at once, in front of everything else: the first slabs of the forward sweep, the row ids and the
+  // inverse pivots of the wave's first 64 * LANES_K rows (both kept in registers to the end: the scaling between the sweeps and
+  // the store at the end then need no further trip); then the right-hand side (one dependent trip).  Waves with more rows go
+  // through the same three passes chunk by chunk for the rest.
   constexpr int K = LANES_K;
-  for (int base = 0; base < nr; base += 64 * K) {
+  LaneSlot<E> A[PF];
+  lane_load<E, PF>(A, s0, meta, val, lane);
+  int idx0[K];
+  double d0[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int t = 64 * k + (int)lane;
+    idx0[k] = t < nr ? rows[rb + t] : -1;
+    d0[k] = t < nr ? dinv[rb + t] : 0.0;
+  }
+  {
+    double v[K][NCOMP];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) v[k][c] = idx0[k] >= 0 ? b[(size_t)idx0[k] * NCOMP + c] : 0.0;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if (idx0[k] >= 0) {
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c) xs[(64 * k + (int)lane) * NCOMP + c] = v[k][c];
+      }
+  }
+  for (int base = 64 * K; base < nr; base += 64 * K) {
     int idx[K];
     double v[K][NCOMP];
 #pragma unroll
@@ -934,8 +960,17 @@ __global__ __launch_bounds__(64) void k_ilu_solve_lanes(const int32_t *__restric
   for (int c = 0; c < NCOMP; ++c) xs[(nr + lane) * NCOMP + c] = 0.0;  // the scratch rows of the idle slots
   const uint32_t scratch = (uint32_t)(nr + lane) * (8u * NCOMP);
   __builtin_amdgcn_wave_barrier();
-  lane_sweep<NCOMP, E, PF>(s0, s1, meta, val, lane, scratch);  // y = L^{-1} b
-  for (int base = 0; base < nr; base += 64 * K) {           // y *= D^{-1} (inverse pivots stored in the wave's row order)
+  lane_sweep<NCOMP, E, PF>(A, s0, s1, meta, val, lane, scratch);  // y = L^{-1} b
+  lane_load<E, PF>(A, s1, meta, val, lane);                       // (the backward sweep's first slabs fly during the scaling)
+#pragma unroll
+  for (int k = 0; k < K; ++k) {                                   // y *= D^{-1} (inverse pivots stored in the wave's row order)
+    const int t = 64 * k + (int)lane;
+    if (t < nr) {
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) xs[t * NCOMP + c] *= d0[k];
+    }
+  }
+  for (int base = 64 * K; base < nr; base += 64 * K) {
     double d[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -952,7 +987,7 @@ __global__ __launch_bounds__(64) void k_ilu_solve_lanes(const int32_t *__restric
     }
   }
   __builtin_amdgcn_wave_barrier();
-  lane_sweep<NCOMP, E, PF>(s1, s2, meta, val, lane, scratch);  // x = U^{-1} y
+  lane_sweep<NCOMP, E, PF>(A, s1, s2, meta, val, lane, scratch);  // x = U^{-1} y
   double dot = 0.0;  // b . x over this wave's rows (CG's g.h right after the preconditioner, Prec.hpp:388 / SolverCG)
   for (int base = 0; base < nr; base += 64 * K) {
     int idx[K];
@@ -960,7 +995,7 @@ __global__ __launch_bounds__(64) void k_ilu_solve_lanes(const int32_t *__restric
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const int t = base + 64 * k + (int)lane;
-      idx[k] = t < nr ? rows[rb + t] : -1;
+      idx[k] = base == 0 ? idx0[k] : (t < nr ? rows[rb + t] : -1);
     }
     if (dot_partial) {
 #pragma unroll

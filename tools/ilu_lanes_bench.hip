@@ -29,7 +29,9 @@ __global__ __launch_bounds__(64) void k_bench(int ticks, int rows, int hot, cons
   for (int t = lane; t < (rows + 64) * NCOMP; t += 64) xs[t] = 1.0 + 1e-3 * t;
   __builtin_amdgcn_wave_barrier();
   const int s0 = hot ? 0 : blockIdx.x * ticks;
-  nsx::lane_sweep<NCOMP, E, PF>(s0, s0 + ticks, meta, val, lane, (uint32_t)(rows + lane) * 8u * NCOMP);
+  nsx::LaneSlot<E> A[PF];
+  nsx::lane_load<E, PF>(A, s0, meta, val, lane);
+  nsx::lane_sweep<NCOMP, E, PF>(A, s0, s0 + ticks, meta, val, lane, (uint32_t)(rows + lane) * 8u * NCOMP);
   double acc = 0.0;
   for (int t = lane; t < rows * NCOMP; t += 64) acc += xs[t];
   if (acc == 123.456) out[blockIdx.x] = acc;
