@@ -291,3 +291,24 @@ def test_colour_all_also_orders_the_pressure_nodes_by_colour_of_the_schur_graph(
         nb = nb[(nb < i) & (d2.pnode_owner[nb] == d2.pnode_owner[i])]
         depth[i] = depth[nb].max() + 1 if len(nb) else 0
     assert depth.max() + 1 <= d2.n_colours_p
+
+
+def test_merge_ranks_builds_blocks_of_consecutive_ranks_within_a_row_limit():
+    """Schur ILU blocks of bench.py: consecutive ranks merged up to a row limit (nsx_set_schur_blocks takes unions of ranks)."""
+    from navierstokes_project_nm4pde_amd.frontend import DoFs, Mesh, merge_ranks
+    d = DoFs(Mesh.cylinder(3, 2).partition(1, 64), "colour")
+    ptr = np.asarray(d.owned_p_ptr)
+    for limit in (1, 20, 96, 10 ** 9):
+        t = merge_ranks(ptr, limit)
+        assert t[0] == ptr[0] and t[-1] == ptr[-1] and (np.diff(t) > 0).all()
+        assert np.isin(t, ptr).all()                                    # block boundaries are rank boundaries
+        sizes, ranks = np.diff(t), np.diff(ptr)
+        assert (sizes <= max(limit, ranks.max())).all()                 # a rank larger than the limit stays a block of its own
+        if limit >= ptr[-1] - ptr[0]:
+            assert len(t) == 2
+    t = merge_ranks(ptr, 96)
+    # greedy: a block could not have taken the next rank as well
+    nxt = np.searchsorted(ptr, t[1:-1])
+    assert ((ptr[nxt + 1] - t[:-2]) > 96).all()
+    empty = np.array([0, 0, 5, 5, 9], dtype=np.int32)                   # empty ranks do not produce empty blocks
+    assert merge_ranks(empty, 4).tolist() == [0, 5, 9]

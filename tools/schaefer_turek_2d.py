@@ -49,6 +49,8 @@ def run(level, deltat, T, n_sub):
         cd, cl = force_coefficients(2, *dev.compute_forces(), mean_v=inlet.mean_velocity())
         cds.append(cd)
         cls.append(cl)
+        if step % 100 == 99:  # progress (a silent GPU job is taken to be hung after 7 minutes)
+            print("level %d: step %d / %d, c_D %.4f c_L %.4f" % (level, step + 1, n_steps, cd, cl), file=sys.stderr, flush=True)
     dp = pressure_difference(mesh, dofs, dev.solution)   # p(0.15, 0.2) - p(0.25, 0.2) at t = T
     wall = time.perf_counter() - t0
     dev.close()
