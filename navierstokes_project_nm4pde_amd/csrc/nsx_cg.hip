@@ -23,7 +23,6 @@ namespace nsx {
 constexpr int CG_THREADS = 256;  // 256 or 512 (two halves of 256: each streams the slabs of every other 16-row round of the block)
 constexpr int CG_NW = CG_THREADS / 64, CG_NG = CG_THREADS / 16;  // waves, 16-lane row groups
 constexpr int CG_MAXB = 256;    // rows of one Schur block: one thread per row in the update phases
-constexpr int CG_PRES_ROWS = 128;  // up to this many rows per block the explicit inverses can stay in registers (k_cg_schur<6>: 96 rows, <8>: 128)
 constexpr int CG_MAX_WG = 1024;
 constexpr int CG_NV = 3;        // values per exchange
 constexpr int CG_RING = 4;      // mailbox rows in flight; row (e + 2) % 4 is emptied at exchange e
