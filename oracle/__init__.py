@@ -60,6 +60,7 @@ def lib(mt=False):
         L.orc_destroy.argtypes = [vp]
         L.orc_set_ranks.argtypes = [vp, C.c_int, _i32p, _i32p]
         L.orc_set_schur_blocks.argtypes = [vp, C.c_int, _i32p]
+        L.orc_set_compact.argtypes = [vp, C.c_int]
         L.orc_assemble.argtypes = [vp, C.c_int]
         L.orc_assemble_time_step.argtypes = [vp, C.c_int]
         L.orc_add_rhs.argtypes = [vp, C.c_int, _i32p, _f64p]
@@ -106,7 +107,7 @@ def _cd(a):
 class Oracle:
     """One `NavierStokes` problem instance of the restated reference algorithm (raw arrays in, raw arrays out)."""
 
-    def __init__(self, dofs, tables, nu, deltat, threads=1):
+    def __init__(self, dofs, tables, nu, deltat, threads=1, compact=False):
         """threads = 1: the serial restatement (liboracle.so).  threads > 1: the OpenMP build of the same source
         (liboracle_mt.so) on that many threads — only bench.py's cpu_baseline leg uses it."""
         L = lib(mt=threads > 1)
@@ -126,6 +127,8 @@ class Oracle:
                                float(nu), float(deltat))
         if dofs.n_subdomains > 1:
             self.set_ranks(dofs.owned_u_ptr, dofs.owned_p_ptr)
+        if compact:  # scalar P2 operator for the products with system(0,0) and its ILU(0): bench.py's "best CPU" leg, not the reference's layout
+            L.orc_set_compact(self._h, 1)
 
     def __del__(self):
         try:

@@ -54,6 +54,11 @@ struct orc {
   double *diag_D, *diag_D_inv, *neg_diag_D_inv, *lump_M;
   double *ay_tmp, *ay_tmp2;
   double alpha_simple, alpha_asimple;
+  /* compact storage of block (0,0) (orc_set_compact; BASELINE.md section 2 (ii), the "best CPU" variant of bench.py's
+   * cpu_baseline): the scalar P2 graph and, per entry, its position in the padded graph of the reference */
+  int compact, cs_n;
+  int32_t *cs_rp, *cs_ci, *cs_pos, *cs_rank;
+  double *cs_F, *cs_ilu;
 };
 
 /* threads the library was built for and will use (1 = the serial restatement) */
@@ -458,6 +463,12 @@ void orc_destroy(orc *o) {
   free(o->lump_M);
   free(o->ay_tmp);
   free(o->ay_tmp2);
+  free(o->cs_rp);
+  free(o->cs_ci);
+  free(o->cs_pos);
+  free(o->cs_rank);
+  free(o->cs_F);
+  free(o->cs_ilu);
   free(o);
 }
 
@@ -907,6 +918,108 @@ static sc_result cg(op_fn A, void *actx, double *x, const double *b, op_fn P, vo
   return res;
 }
 
+/* ------------------------------------------------------------------ compact storage of block (0,0)
+ * NOT the reference's layout: the reference stores every coupling of the dim velocity components of two P2 nodes
+ * (NS3D:109-119), i.e. dim^2 entries of which dim carry the same scalar value and the others are explicit zeros.  With
+ * orc_set_compact(o, 1) the products with system(0,0) and its per-rank ILU(0) run on the scalar P2 x P2 operator applied to
+ * the dim interleaved components -- the same algorithm and the same numbers up to rounding (the cross-component fill of the
+ * padded ILU(0) is exactly zero), 1/dim^2 of the matrix traffic.  Used only by bench.py's cpu_baseline leg ("best CPU").
+ * Assembly, Dirichlet rows, the Schur product and the rectangular blocks keep the reference-shaped layout. */
+void orc_set_compact(orc *o, int on) {
+  o->compact = on != 0;
+  if (!o->compact || o->cs_rp) return;
+  const int dim = o->dim, n = o->n_u / dim;
+  const int32_t *rp = o->rp[0], *ci = o->ci[0];
+  o->cs_n = n;
+  o->cs_rp = xcalloc((size_t)n + 1, sizeof(int32_t));
+  for (int i = 0; i < n; ++i) {
+    int c = 0;
+    for (int k = rp[dim * i]; k < rp[dim * i + 1]; ++k) c += ci[k] % dim == 0;
+    o->cs_rp[i + 1] = o->cs_rp[i] + c;
+  }
+  o->cs_ci = xmalloc((size_t)o->cs_rp[n] * sizeof(int32_t));
+  o->cs_pos = xmalloc((size_t)o->cs_rp[n] * sizeof(int32_t));
+  for (int i = 0; i < n; ++i) {
+    int q = o->cs_rp[i];
+    for (int k = rp[dim * i]; k < rp[dim * i + 1]; ++k)
+      if (ci[k] % dim == 0) {
+        o->cs_ci[q] = ci[k] / dim;
+        o->cs_pos[q++] = k;
+      }
+  }
+  o->cs_F = xcalloc((size_t)o->cs_rp[n], sizeof(double));
+  o->cs_ilu = xcalloc((size_t)o->cs_rp[n], sizeof(double));
+}
+
+typedef struct {
+  int n, dim; /* n scalar rows, dim interleaved components */
+  const int32_t *rp, *ci;
+  const double *v;
+} csr3_ctx;
+static void op_csr3(void *c, double *dst, const double *src) {
+  const csr3_ctx *m = c;
+  const int dim = m->dim;
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < m->n; ++i) {
+    double s[3] = {0, 0, 0};
+    for (int k = m->rp[i]; k < m->rp[i + 1]; ++k) {
+      const double a = m->v[k];
+      const double *xj = src + (size_t)m->ci[k] * dim;
+      for (int d = 0; d < dim; ++d) s[d] += a * xj[d];
+    }
+    for (int d = 0; d < dim; ++d) dst[(size_t)i * dim + d] = s[d];
+  }
+}
+typedef struct {
+  int n, dim;
+  const int32_t *rp, *ci;
+  const double *lu;
+  int nb;
+  const int32_t *bptr; /* node units */
+} ilu3_ctx;
+/* orc_ilu0_solve on the scalar factors for dim interleaved right-hand sides */
+static void op_ilu3(void *c, double *x, const double *b) {
+  const ilu3_ctx *m = c;
+  const int dim = m->dim;
+  const int32_t *rp = m->rp, *ci = m->ci;
+  const double *lu = m->lu;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int blk = 0; blk < m->nb; ++blk) {
+    const int r0 = m->bptr[blk], r1 = m->bptr[blk + 1];
+    for (int i = r0; i < r1; ++i) {
+      double s[3] = {0, 0, 0};
+      for (int d = 0; d < dim; ++d) s[d] = b[(size_t)i * dim + d];
+      int k = rp[i];
+      for (; k < rp[i + 1] && ci[k] < i; ++k)
+        if (ci[k] >= r0)
+          for (int d = 0; d < dim; ++d) s[d] -= lu[k] * x[(size_t)ci[k] * dim + d];
+      for (int d = 0; d < dim; ++d) x[(size_t)i * dim + d] = s[d];
+    }
+    for (int i = r0; i < r1; ++i) {
+      const double di = lu[row_find(rp, ci, i, i)];
+      for (int d = 0; d < dim; ++d) x[(size_t)i * dim + d] *= di;
+    }
+    for (int i = r1 - 1; i >= r0; --i) {
+      double s[3] = {0, 0, 0};
+      for (int d = 0; d < dim; ++d) s[d] = x[(size_t)i * dim + d];
+      for (int k = rp[i + 1] - 1; k >= rp[i] && ci[k] > i; --k)
+        if (ci[k] < r1)
+          for (int d = 0; d < dim; ++d) s[d] -= lu[k] * x[(size_t)ci[k] * dim + d];
+      for (int d = 0; d < dim; ++d) x[(size_t)i * dim + d] = s[d];
+    }
+  }
+}
+/* system(0,0) in compact form + its ILU(0) per rank: called by orc_prec_initialize when compact */
+static void compact_refresh(orc *o) {
+  const int n = o->cs_n;
+#pragma omp parallel for schedule(static)
+  for (int k = 0; k < o->cs_rp[n]; ++k) o->cs_F[k] = o->sys[0][o->cs_pos[k]];
+  free(o->cs_rank);
+  o->cs_rank = xmalloc(((size_t)o->n_ranks + 1) * sizeof(int32_t));
+  for (int r = 0; r <= o->n_ranks; ++r) o->cs_rank[r] = o->rank_u[r] / o->dim;
+  orc_ilu0_factor(n, o->cs_rp, o->cs_ci, o->cs_F, o->n_ranks, o->cs_rank, o->cs_ilu);
+}
+
 /* ------------------------------------------------------------------ operators */
 typedef struct {
   int n;
@@ -932,7 +1045,12 @@ static void op_ilu(void *c, double *dst, const double *src) {
 /* BlockSparseMatrix::vmult: dst_u = F x_u + block(0,1) x_p ; dst_p = block(1,0) x_u (block (1,1) is empty). */
 void orc_system_vmult(orc *o, double *dst, const double *src) {
   const int n_u = o->n_u, n_p = o->n_p;
-  orc_spmv(n_u, o->rp[0], o->ci[0], o->sys[0], src, dst);
+  if (o->compact && o->cs_F) {
+    csr3_ctx Fc = {o->cs_n, o->dim, o->cs_rp, o->cs_ci, o->cs_F};
+    op_csr3(&Fc, dst, src);
+  } else {
+    orc_spmv(n_u, o->rp[0], o->ci[0], o->sys[0], src, dst);
+  }
 #pragma omp parallel for schedule(static)
   for (int i = 0; i < n_u; ++i) {
     double s = 0;
@@ -998,7 +1116,8 @@ void orc_prec_initialize(orc *o, int type) {
   /* B->mmult(negative_S, *B_T, V): B = block(1,0), B_T = block(0,1) */
   mmult(&o->S, n_p, o->rp[2], o->ci[2], o->sys[2], n_p, o->rp[1], o->ci[1], o->sys[1], V);
   /* preconditioner_F.initialize(*F); preconditioner_S.initialize(negative_S) */
-  orc_ilu0_factor(n_u, rp, ci, F, o->n_ranks, o->rank_u, o->ilu_F);
+  if (o->compact) compact_refresh(o); /* scalar operator + scalar ILU(0) per rank (bench.py's "best CPU" leg only) */
+  else orc_ilu0_factor(n_u, rp, ci, F, o->n_ranks, o->rank_u, o->ilu_F);
   free(o->ilu_S);
   o->ilu_S = xcalloc((size_t)o->S.rp[n_p], sizeof(double));
   int nb;
@@ -1027,11 +1146,16 @@ static void prec_vmult(void *c, double *dst, const double *src) {
   const int n_u = o->n_u, n_p = o->n_p;
   const double tol = pc->inner_rtol;
   const int maxit = pc->inner_maxiter;
-  csr_ctx Fm = {n_u, o->rp[0], o->ci[0], o->sys[0]};
+  csr_ctx Fm_padded = {n_u, o->rp[0], o->ci[0], o->sys[0]};
+  csr3_ctx Fm_compact = {o->cs_n, o->dim, o->cs_rp, o->cs_ci, o->cs_F};
+  ilu3_ctx PF_compact = {o->cs_n, o->dim, o->cs_rp, o->cs_ci, o->cs_ilu, o->n_ranks, o->cs_rank};
+  const op_fn opF = o->compact ? op_csr3 : op_csr, opPF = o->compact ? op_ilu3 : op_ilu;
+  void *Fm_ = o->compact ? (void *)&Fm_compact : (void *)&Fm_padded;
   csr_ctx Bm = {n_p, o->rp[2], o->ci[2], o->sys[2]};   /* B   = block(1,0) */
   csr_ctx BTm = {n_u, o->rp[1], o->ci[1], o->sys[1]};  /* B_T = block(0,1) */
   csr_ctx Sm = {n_p, o->S.rp, o->S.ci, o->S.v};
-  ilu_ctx PF = {n_u, o->rp[0], o->ci[0], o->ilu_F, o->n_ranks, o->rank_u};
+  ilu_ctx PF_padded = {n_u, o->rp[0], o->ci[0], o->ilu_F, o->n_ranks, o->rank_u};
+  void *PF_ = o->compact ? (void *)&PF_compact : (void *)&PF_padded;
   int nb;
   const int32_t *bp = schur_blocks(o, &nb);
   ilu_ctx PS = {n_p, o->S.rp, o->S.ci, o->ilu_S, nb, bp};
@@ -1043,7 +1167,7 @@ static void prec_vmult(void *c, double *dst, const double *src) {
     double *yp = dup_mem(src_p, (size_t)n_p * sizeof(double));
     double *tmp = dup_mem(src_p, (size_t)n_p * sizeof(double));
     double *tmp2 = dup_mem(src_u, (size_t)n_u * sizeof(double));
-    count_F(pc, gmres(op_csr, &Fm, yu, src_u, op_ilu, &PF, n_u, tol * v_norm(n_u, src_u), maxit)); /* :382 */
+    count_F(pc, gmres(opF, Fm_, yu, src_u, opPF, PF_, n_u, tol * v_norm(n_u, src_u), maxit)); /* :382 */
     op_csr(&Bm, tmp, yu);                                                                           /* :385 */
     v_add(n_p, tmp, -1.0, src_p);                                                                   /* :386 */
     count_S(pc, cg(op_csr, &Sm, yp, tmp, op_ilu, &PS, n_p, tol * v_norm(n_p, tmp), maxit));         /* :388-390 */
@@ -1051,7 +1175,7 @@ static void prec_vmult(void *c, double *dst, const double *src) {
     op_csr(&BTm, tmp2, dst_p);                                                                      /* :398 */
     double *res = xcalloc(n_u, sizeof(double));                                                     /* :401 */
     v_copy(n_u, dst_u, yu);                                                                         /* :402 */
-    count_F(pc, gmres(op_csr, &Fm, res, tmp2, op_ilu, &PF, n_u, tol * v_norm(n_u, tmp2), maxit));   /* :403-405 */
+    count_F(pc, gmres(opF, Fm_, res, tmp2, opPF, PF_, n_u, tol * v_norm(n_u, tmp2), maxit));   /* :403-405 */
     v_sadd(n_u, dst_u, -1., 1., res); /* dst.block(0).sadd(-1,res): dst = -dst + res                   :406 */
     free(yu);
     free(yp);
@@ -1062,7 +1186,7 @@ static void prec_vmult(void *c, double *dst, const double *src) {
     double *sol1_u = dup_mem(src_u, (size_t)n_u * sizeof(double));
     double *sol1_p = dup_mem(src_p, (size_t)n_p * sizeof(double));
     double *temp_1 = dup_mem(src_p, (size_t)n_p * sizeof(double));
-    count_F(pc, gmres(op_csr, &Fm, sol1_u, src_u, op_ilu, &PF, n_u, tol * v_norm(n_u, src_u), maxit)); /* :173 */
+    count_F(pc, gmres(opF, Fm_, sol1_u, src_u, opPF, PF_, n_u, tol * v_norm(n_u, src_u), maxit)); /* :173 */
     op_csr(&Bm, temp_1, sol1_u);                                                                        /* :175 */
     v_add(n_p, temp_1, -1.0, src_p); /* temp_1 -= src.block(1)                                             :176 */
     count_S(pc, cg(op_csr, &Sm, sol1_p, temp_1, op_ilu, &PS, n_p, tol * v_norm(n_p, temp_1), maxit));   /* :179-182 */
@@ -1079,7 +1203,7 @@ static void prec_vmult(void *c, double *dst, const double *src) {
     free(tmp);
   } else if (pc->type == ORC_ASIMPLE) { /* Prec:254-311 */
     double *tmp_u = xcalloc(n_u, sizeof(double)), *tmp_p = xcalloc(n_p, sizeof(double));                 /* :266 */
-    count_F(pc, gmres(op_csr, &Fm, dst_u, src_u, op_ilu, &PF, n_u, tol * v_norm(n_u, src_u), maxit));    /* :271-273 */
+    count_F(pc, gmres(opF, Fm_, dst_u, src_u, opPF, PF_, n_u, tol * v_norm(n_u, src_u), maxit));    /* :271-273 */
     op_csr(&Bm, dst_p, dst_u);                                                                            /* :280 */
     v_sadd(n_p, dst_p, -1.0, 1.0, src_p); /* dst1.sadd(-1.0, src1): dst1 = -dst1 + src1                      :281 */
     v_copy(n_p, tmp_p, dst_p);                                                                            /* :282 */
@@ -1104,7 +1228,7 @@ static void prec_vmult(void *c, double *dst, const double *src) {
     v_copy(n_p, yp, dst_p);                 /* :504 */
     { /* F->vmult(yu,yu) :507 — Epetra multiplies out of place when source and destination alias [lib] */
       double *t = xmalloc((size_t)n_u * sizeof(double));
-      op_csr(&Fm, t, yu);
+      opF(Fm_, t, yu);
       v_copy(n_u, yu, t);
       free(t);
     }

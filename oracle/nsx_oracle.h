@@ -53,6 +53,10 @@ void orc_destroy(orc *);
 void orc_set_ranks(orc *, int n_ranks, const int32_t *u_ptr_nodes, const int32_t *p_ptr_nodes);
 /* Optional coarser ILU blocks for the Schur matrix (unions of consecutive ranks); default = ranks. */
 void orc_set_schur_blocks(orc *, int n_blocks, const int32_t *p_ptr_nodes);
+/* Compact storage of block (0,0) for the products with system(0,0) and its per-rank ILU(0): the scalar P2 operator on dim
+ * interleaved components instead of the reference's padded dim x dim couplings.  Same algorithm, same numbers up to rounding;
+ * NOT the reference's layout -- bench.py's "best CPU" baseline only. */
+void orc_set_compact(orc *, int on);
 
 /* NavierStokes::assemble (NS3D:163-324 / NS2D:164-325 / Conv:187-357), without the Dirichlet part. */
 void orc_assemble(orc *, int flags);

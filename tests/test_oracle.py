@@ -351,3 +351,32 @@ def test_bench_state_transfer_between_numberings():
     Y = db.support_points
     expect = np.sin(3 * Y[:, 0]) + 2 * Y[:, 1] ** 2 - Y[:, 2] + 0.25 * (np.arange(db.n_dofs) % 3) * (np.arange(db.n_dofs) < db.n_u)
     assert np.array_equal(y, expect)
+
+
+@pytest.mark.parametrize("dim,prec", [(3, 0), (2, 3), (3, 2)])
+def test_compact_storage_mode_equals_the_reference_shaped_layout(dim, prec):
+    """orc_set_compact (bench.py's "best CPU" baseline): products with system(0,0) and its per-rank ILU(0) on the scalar P2
+    operator instead of the reference's padded dim x dim couplings -- the same algorithm, so the same iteration history and
+    the same solution up to rounding (the cross-component fill of the padded ILU(0) is exactly zero)."""
+    import oracle
+    from navierstokes_project_nm4pde_amd.problem import InletVelocity, cylinder_boundary_values
+    p = Problem("cylinder", dim, 1 if dim == 3 else 2, n_sub=3)
+    out = []
+    for compact in (False, True):
+        o = oracle.Oracle(p.dofs, p.tables, p.nu, p.deltat, compact=compact)
+        u = p.smooth_velocity()
+        o.solution[:] = u
+        o.solution_owned[:] = u
+        o.assemble(oracle.TEMAM)
+        o.apply_boundary_values(*cylinder_boundary_values(p.dofs, InletVelocity(dim, 2 if dim == 3 else 3), p.deltat))
+        x = np.random.default_rng(3).standard_normal(p.dofs.n_dofs)
+        y = o.system_vmult(x) if not compact else None
+        st = o.solve_time_step(prec, tol_abs=1e-10, inner_rtol=1e-9)
+        yc = o.system_vmult(x)                                  # (compact: the scalar operator exists after the first initialize)
+        out.append((st, np.array(o.solution_owned), y if y is not None else yc))
+    (s0, x0, y0), (s1, x1, y1) = out
+    assert s0["status"] == 0 and s1["status"] == 0
+    for key in ("outer_iterations", "inner_F_iterations", "inner_S_iterations"):
+        assert abs(s0[key] - s1[key]) <= max(1, 0.02 * s0[key]), key
+    assert np.abs(x0 - x1).max() < 1e-8 * np.abs(x0).max()
+    assert np.abs(y0 - y1).max() < 1e-13 * np.abs(y0).max()
