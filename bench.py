@@ -47,17 +47,63 @@ KERNEL_OF = {"mgs_sweep": "void nsx::k_mgs_one<8, 10>", "add_and_dot": "void nsx
              "axpby": "nsx::k_axpby", "spmv_S": "void nsx::k_spmv_csr<32>", "cg_S": "nsx::k_cg_schur"}
 
 
-def pmc_traffic(scope):
-    """HBM-side bytes per launch from the COMMITTED rocprofv3 --pmc passes of this same command (FETCH_SIZE and
-    WRITE_SIZE in separate passes, values in KiB; gfx950 FETCH_SIZE counts 64 B per 128-B request, so it is doubled:
-    /opt/skills/guides/MI355X_MICROARCH.md section HBM).  A constant read from a profile, not measured in this run (PMC
-    counters need rocprofv3 around the process); None when no profile is committed for the kernel."""
+def pmc_live(argv_tail, log=sys.stderr):
+    """HBM counters of THIS invocation's workload: two child runs of this file under `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE
+    in passes of their own, kernel trace only: /opt/skills/guides/MI355X_MICROARCH.md section HBM), one timed step each, started
+    BEFORE this process touches the GPU.  Returns {kernel symbol: {"launches", "FETCH_SIZE_KB_avg", "WRITE_SIZE_KB_avg"}} or
+    None (no rocprofv3, already under a profiler, a pass failed) -- then the committed profile is quoted and says so."""
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_summary
+    out, tmp = {}, tempfile.mkdtemp(prefix="nsx_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            t0 = time.time()
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "1", "--warmup", "1", "--spinup", "2", "--no-cpu", "--profile-steps", "0", "--pmc", "off"] + argv_tail
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=420)
+            if r.returncode != 0:
+                print("bench.py: rocprofv3 --pmc %s pass failed (rc %d): %s" % (counter, r.returncode, r.stderr.decode(errors="replace")[-400:]), file=log)
+                return None
+            for k, counters in pmc_summary.collect(d).items():
+                for c, (total, ids) in counters.items():
+                    e = out.setdefault(k, {})
+                    e["launches"] = len(ids)
+                    e[c + "_KB_avg"] = total / max(1, len(ids))
+            print("bench.py: rocprofv3 --pmc %s pass: %.0f s" % (counter, time.time() - t0), file=log, flush=True)
+    except (OSError, subprocess.SubprocessError, ValueError, KeyError) as e:
+        print("bench.py: live PMC passes not available: %s: %s" % (type(e).__name__, e), file=log)
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
+def pmc_traffic(scope, live=None):
+    """HBM-side bytes per launch of the kernel behind `scope` (FETCH_SIZE and WRITE_SIZE in separate passes, values in KiB; gfx950
+    FETCH_SIZE counts 64 B per 128-B request, so it is doubled: /opt/skills/guides/MI355X_MICROARCH.md section HBM).  From the
+    live passes of this invocation (pmc_live) when there are any, else the constant of the COMMITTED passes of this same command;
+    (None, None) when neither has the kernel."""
+    def of(tab):
+        e = tab[KERNEL_OF[scope]]
+        return (2.0 * e["FETCH_SIZE_KB_avg"] + e["WRITE_SIZE_KB_avg"]) * 1024.0
+    if live:
+        try:
+            return of(live), "live"
+        except KeyError:
+            pass
     for rel in (PMC_PROFILE, "profiles/r02_pmc_fetch_write_per_kernel.json"):
         try:
             with open(os.path.join(ROOT, rel)) as f:
-                tab = json.load(f)
-            e = tab[KERNEL_OF[scope]]
-            return (2.0 * e["FETCH_SIZE_KB_avg"] + e["WRITE_SIZE_KB_avg"]) * 1024.0, rel
+                return of(json.load(f)), rel
         except (OSError, KeyError, ValueError):
             continue
     return None, None
@@ -331,6 +377,9 @@ def main():
     ap.add_argument("--cpu-only", action="store_true", help="only the cpu_baseline leg (after a short GPU run that provides its state)")
     ap.add_argument("--layout-table", metavar="FILE", help="write the preconditioner-layout iteration table to FILE and exit")
     ap.add_argument("--profile-steps", type=int, default=5)
+    ap.add_argument("--pmc", choices=("auto", "off"), default="auto",
+                    help="auto: on one GPU with the cpu_baseline leg, measure roofline.traffic in two child runs under rocprofv3 --pmc "
+                         "(FETCH_SIZE, WRITE_SIZE; ~1 min each); off: quote the committed profile")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -347,6 +396,10 @@ def main():
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    live_pmc = None
+    if args.pmc == "auto" and world == 1 and not args.no_cpu and not args.cpu_only and not args.layout_table:
+        tail = ["--ranks", str(args.ranks), "--schur-blocks", str(args.schur_blocks), "--ordering", args.ordering, "--balance", args.balance]
+        live_pmc = pmc_live(tail + (["--level", str(args.level)] if args.level is not None else []))
     if "NSX_BENCH_DEVICE" in os.environ:  # development only: several ranks on one card
         local_rank = int(os.environ["NSX_BENCH_DEVICE"])
     import torch
@@ -418,14 +471,22 @@ def main():
     roof = None
     if dom:
         a = kernels[dom]["alg_GBps"]
-        traffic, traffic_src = pmc_traffic(dom)
+        traffic, traffic_src = pmc_traffic(dom, live_pmc)
         roof = {"kernel": dom, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
-                "traffic": traffic, "wasted": (traffic / table[dom]["bytes_per_launch"]) if traffic else None, "traffic_source": ("constant from the committed rocprofv3 --pmc profile %s, not measured in this run" % traffic_src)
-                if traffic_src else None,
+                "traffic": traffic, "wasted": (traffic / table[dom]["bytes_per_launch"]) if traffic else None,
+                "traffic_source": ("measured in this invocation: child runs of this command under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), "
+                                   "average over the kernel's launches" if traffic_src == "live" else
+                                   "constant from the committed rocprofv3 --pmc profile %s, not measured in this run" % traffic_src) if traffic_src else None,
                 "algorithmic_bytes": table[dom]["bytes_per_launch"], "avg_us": kernels[dom]["avg_us"], "share_of_kernel_time": kernels[dom]["share"]}
         if "spmv_F" in kernels and kernels["spmv_F"]["alg_GBps"]:
             roof["spmv_F_GBps"] = kernels["spmv_F"]["alg_GBps"]
             roof["spmv_F_frac"] = kernels["spmv_F"]["alg_GBps"] / HBM_PEAK_GBS
+    if live_pmc:
+        for k, v in kernels.items():
+            t, src = pmc_traffic(k, live_pmc) if k in KERNEL_OF else (None, None)
+            if src == "live":
+                v["pmc_bytes_per_launch"] = t
+                v["wasted"] = t / table[k]["bytes_per_launch"] if table[k]["bytes_per_launch"] > 0 else None
     use_strong = world > 1 and args.scaling == "strong" and strong
     n = max(1, len(stats))
     out = {
