@@ -44,7 +44,7 @@ NU, DT = 1e-3, 2e-4
 # scope name used by the library's HIP-event timer -> kernel symbol in rocprofv3 output
 KERNEL_OF = {"mgs_sweep": "void nsx::k_mgs_one<8, 10>", "add_and_dot": "void nsx::k_reduce<1>", "dot": "void nsx::k_reduce<0>", "spmv_F": "void nsx::k_spmv_blocked<3, 16>",
              "ilu_solve_F": "void nsx::k_ilu_solve_lanes<3, 2, 8>", "ilu_solve_S": "nsx::k_ilu_apply_dense",
-             "axpby": "nsx::k_axpby", "spmv_S": "void nsx::k_spmv_csr<32>", "cg_S": "nsx::k_cg_schur"}
+             "axpby": "nsx::k_axpby", "spmv_S": "void nsx::k_spmv_csr<32>", "cg_S": "void nsx::k_cg_schur<6, true>"}
 
 
 def pmc_live(argv_tail, log=sys.stderr):

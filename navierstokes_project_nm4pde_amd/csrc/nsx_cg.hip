@@ -133,6 +133,7 @@ __device__ __forceinline__ bool cg_collect(double (&tot)[NV], unsigned long long
 // whose d entries are staged in LDS once per iteration (~400 gathers per block instead of ~7000).
 constexpr int CG_PF = 8;         // slabs per register set (two sets in flight)
 constexpr int CG_MAX_UCOLS = 1024;
+constexpr int CG_LPOOL = 6656;     // entries of one block's rows held in LDS by the LRES variant (8 + 2 bytes each)
 
 __global__ void k_cg_pack(int64_t n_slots, const int32_t *__restrict__ src, const double *__restrict__ sv, double *__restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -182,17 +183,28 @@ __device__ __forceinline__ void cg_block_spmv(int s0, int s1, const double *__re
 }
 #undef NSX_CG_LOAD
 
-template <int RPG>  // 0: the block inverses are streamed in every iteration; 6 / 8: blocks of at most 96 / 128 rows, inverses in registers
+// RPG  0: the block inverses are streamed in every iteration; 6 / 8: blocks of at most 96 / 128 rows, inverses in registers.
+// LRES true (RPG > 0 only): the block's rows of negative_S_tilde stay in LDS for the whole solve as well (values + 16-bit local
+//      columns, CSR order, at most CG_LPOOL entries: 65 KB of the CU's 160 KB, two workgroups per CU) -- an iteration then reads
+//      nothing from HBM but the neighbours' d and h.  Same lanes, same entries per lane, same sums as the slab stream: bit-identical.
+template <int RPG, bool LRES>
 __global__ __launch_bounds__(CG_THREADS) void k_cg_schur(const int32_t *__restrict__ bptr, const int32_t *__restrict__ u_ptr,
                                                   const int32_t *__restrict__ u_cols, const int32_t *__restrict__ s_ptr,
                                                   const double *__restrict__ sval, const uint16_t *__restrict__ slidx,
                                                   const int32_t *__restrict__ sinfo, const int64_t *__restrict__ dn_off,
                                                   const double *__restrict__ P, const double *__restrict__ b, double *x, double *D0, double *D1,
                                                   double *H, double rtol, int maxiter, unsigned long long *box, unsigned long long *box_other,
-                                                  double *pub_vals, unsigned long long *pub_flag, unsigned long long seq, int *err_dev, int drop_wg) {
-  __shared__ double gs[CG_MAXB], hs[CG_MAXB], ds[CG_MAXB], hvs[CG_MAXB], xs[CG_MAXB], xst[CG_MAX_UCOLS];
+                                                  double *pub_vals, unsigned long long *pub_flag, unsigned long long seq, int *err_dev, int drop_wg,
+                                                  const int32_t *__restrict__ a_rowptr, const double *__restrict__ a_val,
+                                                  const uint16_t *__restrict__ a_lidx) {
+  static_assert(!LRES || RPG > 0, "the LDS-resident operator needs the register-resident block inverses");
+  constexpr int MAXB = RPG > 0 ? 16 * RPG : CG_MAXB;  // rows of the largest block this instantiation serves
+  __shared__ double gs[MAXB], hs[MAXB], ds[MAXB], hvs[MAXB], xs[MAXB], xst[CG_MAX_UCOLS];
   __shared__ double sh[4][CG_NV * 8], bc[CG_NV];
   __shared__ int s_err;
+  __shared__ double lval[LRES ? CG_LPOOL : 1];
+  __shared__ uint16_t lidx[LRES ? CG_LPOOL : 2];
+  __shared__ int lrow[LRES ? MAXB + 1 : 1];
   const int wg = blockIdx.x, tid = threadIdx.x, nwg = gridDim.x;
   if (tid == 0) s_err = 0;
   // leave the other region empty for the next launch (stream order makes this visible to it)
@@ -211,7 +223,7 @@ __global__ __launch_bounds__(CG_THREADS) void k_cg_schur(const int32_t *__restri
   int ucol[NU];
 #pragma unroll
   for (int k = 0; k < NU; ++k) ucol[k] = tid + CG_THREADS * k < nu ? u_cols[u0 + tid + CG_THREADS * k] : -1;
-  if (tid < CG_MAXB) gs[tid] = 0.0;  // rows beyond nb stay 0: the dense product reads gs[] unguarded
+  if (tid < MAXB) gs[tid] = 0.0;  // rows beyond nb stay 0: the dense product reads gs[] unguarded
 
   // h = P_b g on the block, 16 lanes per row (32 rows at a time); result in hs[] and (write-through) in H.  Blocks of up to
   // 128 rows (the usual case) keep the loads of two rows in flight, and the first two rows are fetched by prefetch_P() while
@@ -301,6 +313,39 @@ __global__ __launch_bounds__(CG_THREADS) void k_cg_schur(const int32_t *__restri
     if (own) st_agent(H + r0 + tid, hs[tid]);
   };
 
+  double va[LRES ? 1 : CG_PF];
+  int la[LRES ? 1 : CG_PF];
+  if constexpr (LRES) {
+    const int p0 = a_rowptr[r0], nz = a_rowptr[r0 + nb] - p0;  // nz <= CG_LPOOL (checked on the host)
+    for (int q = tid; q < nz; q += CG_THREADS) {
+      lval[q] = a_val[p0 + q];
+      lidx[q] = a_lidx[p0 + q];
+    }
+    if (tid <= nb) lrow[tid] = a_rowptr[r0 + tid] - p0;
+  }
+  // hvs = (negative_S_tilde restricted to the block's rows) * xst: row q by lane group q % 16, entry e by lane e % 16 -- from LDS
+  // (LRES) or from the slab stream, whose first register set the caller has requested with prefetch_A()
+  auto prefetch_A = [&]() {
+    if constexpr (!LRES) cg_spmv_prefetch(s0, s1, sval, slidx, ht, va, la);
+  };
+  auto block_spmv = [&]() {
+    if constexpr (LRES) {
+#pragma unroll
+      for (int r = 0; r < RPG; ++r) {
+        const int q = grp + CG_NG * r;
+        if (q < nb) {
+          const int e1 = lrow[q + 1];
+          double acc = 0.0;
+          for (int e = lrow[q] + lane; e < e1; e += 16) acc += lval[e] * xst[lidx[e]];
+          acc = cg_group_sum<16>(acc);
+          if (lane == 0) hvs[q] = acc;
+        }
+      }
+    } else {
+      cg_block_spmv(s0, s1, sval, slidx, sinfo, xst, hvs, ht, va, la);
+    }
+  };
+
   // ---- g = A x - b ; h = P g ; sums g.g, b.b, g.h
   double bi = 0.0;
   if (own) {
@@ -310,11 +355,9 @@ __global__ __launch_bounds__(CG_THREADS) void k_cg_schur(const int32_t *__restri
 #pragma unroll
   for (int k = 0; k < NU; ++k)
     if (ucol[k] >= 0) xst[tid + CG_THREADS * k] = x[ucol[k]];
-  double va[CG_PF];
-  int la[CG_PF];
-  cg_spmv_prefetch(s0, s1, sval, slidx, ht, va, la);
+  prefetch_A();
   __syncthreads();
-  cg_block_spmv(s0, s1, sval, slidx, sinfo, xst, hvs, ht, va, la);
+  block_spmv();
   __syncthreads();
   prefetch_P();
   if (own) gs[tid] = hvs[tid] - bi;
@@ -324,7 +367,7 @@ __global__ __launch_bounds__(CG_THREADS) void k_cg_schur(const int32_t *__restri
   {
     const double part[3] = {own ? gs[tid] * gs[tid] : 0.0, own ? bi * bi : 0.0, own ? gs[tid] * hs[tid] : 0.0};
     cg_post<3>(part, box, e, nwg, sh, &s_err, wg == drop_wg);
-    cg_spmv_prefetch(s0, s1, sval, slidx, ht, va, la);  // the operator values of the first iteration ride on the exchange
+    prefetch_A();  // the operator values of the first iteration ride on the exchange
     if (!cg_collect<3>(tot3, box, e++, bc, &s_err)) {
       if (tid == 0) __hip_atomic_store(err_dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (wg == 0 && tid == 0) {
@@ -358,7 +401,7 @@ __global__ __launch_bounds__(CG_THREADS) void k_cg_schur(const int32_t *__restri
       st_agent(Dc + r0 + tid, dcur);
     }
     __syncthreads();
-    cg_block_spmv(s0, s1, sval, slidx, sinfo, xst, hvs, ht, va, la);
+    block_spmv();
     __syncthreads();
     double tot1[1];
     {
@@ -382,7 +425,7 @@ __global__ __launch_bounds__(CG_THREADS) void k_cg_schur(const int32_t *__restri
     {
       const double part[2] = {own ? gs[tid] * gs[tid] : 0.0, own ? gs[tid] * hs[tid] : 0.0};
       cg_post<2>(part, box, e, nwg, sh, &s_err);
-      cg_spmv_prefetch(s0, s1, sval, slidx, ht, va, la);  // next iteration's operator values (wasted once, in the last iteration)
+      prefetch_A();  // next iteration's operator values (wasted once, in the last iteration)
       if (!cg_collect<2>(tot2, box, e++, bc, &s_err)) {
         dead = true;
         break;
@@ -416,7 +459,8 @@ void build_cg_plan(nsx_handle *h) {
   const std::vector<int32_t> &bptr = s.block_ptr_h;
   const int nb = s.n_blocks;
   std::vector<int32_t> u_ptr(nb + 1, 0), u_cols, s_ptr(3 * (size_t)nb + 1, 0), s_info, s_src, tmp;
-  std::vector<uint16_t> s_lidx;
+  std::vector<uint16_t> s_lidx, a_lidx((size_t)g.nnz());
+  pl.max_block_nnz = 0;
   for (int b = 0; b < nb; ++b) {
     const int r0 = bptr[b], r1 = bptr[b + 1], n = r1 - r0;
     tmp.assign(g.colind.begin() + g.rowptr[r0], g.colind.begin() + g.rowptr[r1]);
@@ -425,6 +469,8 @@ void build_cg_plan(nsx_handle *h) {
     if ((int)tmp.size() > CG_MAX_UCOLS) return;  // plan not applicable: the launch-per-operation solver stays in charge
     u_cols.insert(u_cols.end(), tmp.begin(), tmp.end());
     u_ptr[b + 1] = (int32_t)u_cols.size();
+    pl.max_block_nnz = std::max(pl.max_block_nnz, g.rowptr[r1] - g.rowptr[r0]);
+    for (int p = g.rowptr[r0]; p < g.rowptr[r1]; ++p) a_lidx[p] = (uint16_t)(std::lower_bound(tmp.begin(), tmp.end(), g.colind[p]) - tmp.begin());
     for (int half = 0; half < 2; ++half) {  // the even rounds (first half of the workgroup), then the odd ones
       s_ptr[3 * (size_t)b + half] = (int32_t)s_info.size();
       for (int r = half; r * 16 < n; r += 2) {
@@ -456,6 +502,7 @@ void build_cg_plan(nsx_handle *h) {
   pl.s_info.upload(s_info, h->stream);
   pl.s_src.upload(s_src, h->stream);
   pl.s_lidx.upload(s_lidx, h->stream);
+  pl.a_lidx.upload(a_lidx, h->stream);
   pl.s_val.alloc((size_t)pl.n_slots);
   pl.ok = true;
   pl.values_current = false;
@@ -483,18 +530,23 @@ static void cg_setup(nsx_handle *h) {
   int cus = 0, per_cu = 0;
   HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->prm.device));
   int per_cu_res[2] = {0, 0};
-  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_schur<0>, CG_THREADS, 0));
-  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_res[0], k_cg_schur<6>, CG_THREADS, 0));
-  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_res[1], k_cg_schur<8>, CG_THREADS, 0));
+  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_schur<0, false>, CG_THREADS, 0));
+  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_res[0], k_cg_schur<6, false>, CG_THREADS, 0));
+  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_res[1], k_cg_schur<8, false>, CG_THREADS, 0));
   h->cg_max_wg_res[0] = std::min(CG_MAX_WG, per_cu_res[0] * cus);
   h->cg_max_wg_res[1] = std::min(CG_MAX_WG, per_cu_res[1] * cus);
+  int per_cu_lres[2] = {0, 0};
+  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_lres[0], k_cg_schur<6, true>, CG_THREADS, 0));
+  HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_lres[1], k_cg_schur<8, true>, CG_THREADS, 0));
+  h->cg_max_wg_lres[0] = std::min(CG_MAX_WG, per_cu_lres[0] * cus);
+  h->cg_max_wg_lres[1] = std::min(CG_MAX_WG, per_cu_lres[1] * cus);
   h->cg_box.alloc(2 * CG_REGION + 2);
   HIP_CHECK(hipMemsetAsync(h->cg_box.p, 0xff, 2 * CG_REGION * sizeof(unsigned long long), h->stream));
   HIP_CHECK(hipMemsetAsync(h->cg_box.p + 2 * CG_REGION, 0, 2 * sizeof(unsigned long long), h->stream));
   h->cg_max_wg = std::min(CG_MAX_WG, per_cu * cus);
   if (getenv("NSX_DEBUG"))
-    fprintf(stderr, "[nsx] persistent Schur CG: %d CUs x %d resident workgroups, grid <= %d (block inverses in registers: <= 96 rows x %d, <= 128 rows x %d)\n", cus, per_cu,
-            h->cg_max_wg, per_cu_res[0], per_cu_res[1]);
+    fprintf(stderr, "[nsx] persistent Schur CG: %d CUs x %d resident workgroups, grid <= %d (block inverses in registers: <= 96 rows x %d, <= 128 rows x %d; operator in LDS as well: x %d, x %d)\n", cus, per_cu,
+            h->cg_max_wg, per_cu_res[0], per_cu_res[1], per_cu_lres[0], per_cu_lres[1]);
 }
 
 // CG on negative_S_tilde with the explicit block inverses as preconditioner, one launch.  Returns false when the launch-per-
@@ -505,10 +557,13 @@ bool cg_schur_persistent(nsx_handle *h, double *x, const double *b, double rtol,
   if (h->comm || !s.dense || s.max_rows > CG_MAXB || !pl.ok || !pl.values_current) return false;
   cg_setup(h);
   if (h->cg_max_wg == 0 || s.n_blocks > h->cg_max_wg) return false;
-  static const bool pres_ok = !(getenv("NSX_CG_PRES") && atoi(getenv("NSX_CG_PRES")) == 0);
+  const bool pres_ok = !(getenv("NSX_CG_PRES") && atoi(getenv("NSX_CG_PRES")) == 0);  // read per solve: the tests switch it
   // rows per group of the register-resident variant: the smallest that holds the largest block, if its grid is resident
   const int rpg = !pres_ok ? 0 : (s.max_rows <= 96 && s.n_blocks <= h->cg_max_wg_res[0]) ? 6 : (s.max_rows <= 128 && s.n_blocks <= h->cg_max_wg_res[1]) ? 8 : 0;
   const bool pres = rpg > 0;
+  const bool lres_ok = !(getenv("NSX_CG_LRES") && atoi(getenv("NSX_CG_LRES")) == 0);
+  // ... and the block's rows of the operator in LDS, if every block fits the pool and that grid is resident too
+  const bool lres = lres_ok && pres && pl.max_block_nnz <= CG_LPOOL && s.n_blocks <= h->cg_max_wg_lres[rpg == 6 ? 0 : 1];
   const int n = h->n_p;
   if ((int)h->cg_vec.n < 3 * n) h->cg_vec.alloc((size_t)3 * n);
   double *D0 = h->cg_vec.p, *D1 = D0 + n, *H = D1 + n;
@@ -521,13 +576,20 @@ bool cg_schur_persistent(nsx_handle *h, double *x, const double *b, double rtol,
   {
     LaunchScope ls(h, "cg_S", 0.0);
     pe = ls.e;
-#define NSX_CG_GO(PRES_)                                                                                                                              \
-  hipLaunchKernelGGL(k_cg_schur<PRES_>, dim3(s.n_blocks), dim3(CG_THREADS), 0, h->stream, s.block_ptr.p, pl.u_ptr.p, pl.u_cols.p, pl.s_ptr.p, pl.s_val.p, \
-                     pl.s_lidx.p, pl.s_info.p, s.dn_off.p, s.dn_P.p, b, x, D0, D1, H, rtol, maxiter, box, box_other, pub_vals, pub_flag, seq, err_dev,    \
-                     h->gx_drop_wg)
-    if (rpg == 6) NSX_CG_GO(6); else if (rpg == 8) NSX_CG_GO(8); else NSX_CG_GO(0);
+#define NSX_CG_GO(PRES_, LRES_)                                                                                                                       \
+  hipLaunchKernelGGL((k_cg_schur<PRES_, LRES_>), dim3(s.n_blocks), dim3(CG_THREADS), 0, h->stream, s.block_ptr.p, pl.u_ptr.p, pl.u_cols.p, pl.s_ptr.p,  \
+                     pl.s_val.p, pl.s_lidx.p, pl.s_info.p, s.dn_off.p, s.dn_P.p, b, x, D0, D1, H, rtol, maxiter, box, box_other, pub_vals, pub_flag, seq, \
+                     err_dev, h->gx_drop_wg, h->gS.rowptr.p, h->vSchur.p, pl.a_lidx.p)
+    if (rpg == 6 && lres) NSX_CG_GO(6, true); else if (rpg == 8 && lres) NSX_CG_GO(8, true);
+    else if (rpg == 6) NSX_CG_GO(6, false); else if (rpg == 8) NSX_CG_GO(8, false); else NSX_CG_GO(0, false);
 #undef NSX_CG_GO
+    if (getenv("NSX_DEBUG") && (h->cg_resident != pres || h->cg_lds_resident != lres || !h->cg_variant_said)) {
+      fprintf(stderr, "[nsx] Schur CG variant: block inverses in registers %d (rows per lane group %d), operator in LDS %d (largest block: %d entries)\n", (int)pres, rpg,
+              (int)lres, (int)pl.max_block_nnz);
+      h->cg_variant_said = true;
+    }
     h->cg_resident = pres;
+    h->cg_lds_resident = lres;
   }
   h->cg_parity ^= 1;
   wait_published(h, seq);
@@ -549,7 +611,8 @@ bool cg_schur_persistent(nsx_handle *h, double *x, const double *b, double rtol,
   *status = st;
   // algorithmic bytes: per iteration the matrix (12 B / entry) and the block inverses once, plus the vectors
   // (block inverses resident in registers: read once per solve)
-  if (pe) pe->bytes += (double)(*steps + 1) * (10.0 * h->gS.nnz() + 48.0 * n) + (pres ? 1.0 : (double)(*steps + 1)) * 8.0 * (double)s.dn_entries;
+  // (operator resident in LDS: read once per solve, too)
+  if (pe) pe->bytes += (lres ? 1.0 : (double)(*steps + 1)) * 10.0 * h->gS.nnz() + (double)(*steps + 1) * 48.0 * n + (pres ? 1.0 : (double)(*steps + 1)) * 8.0 * (double)s.dn_entries;
   return true;
 }
 

@@ -187,6 +187,8 @@ struct CgPlan {
   DevBuf<int32_t> u_ptr, u_cols, s_ptr, s_info, s_src;
   DevBuf<uint16_t> s_lidx;
   DevBuf<double> s_val;
+  DevBuf<uint16_t> a_lidx;   // local column of every entry in CSR order (the LDS-resident operator of k_cg_schur<.., true>)
+  int32_t max_block_nnz = 0;
 };
 
 struct ProfEntry {
@@ -280,7 +282,10 @@ struct nsx_handle {
   nsx::CgPlan cgplan;
   nsx::DevBuf<double> cg_vec;
   int cg_parity = 0, cg_max_wg = 0, cg_max_wg_res[2] = {0, 0};  // _res: resident-grid limits of the variants that keep the block inverses in registers (96 / 128 rows)
+  int cg_max_wg_lres[2] = {0, 0};                      // ... and of the variants that keep the operator's rows in LDS as well
   bool cg_resident = false;                            // the last Schur CG ran with the block inverses in registers
+  bool cg_lds_resident = false;                        // ... and with the operator in LDS
+  bool cg_variant_said = false;
   bool cg_disabled = false;
   // ---- force evaluation (compute_forces): obstacle faces + face-quadrature tables
   int ff_n = 0, ff_nq = 0;

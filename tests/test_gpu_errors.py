@@ -266,3 +266,47 @@ def test_time_out_of_a_persistent_grid_falls_back_and_says_so():
         assert np.abs(x0 - x).max() < 1e-9 * np.abs(x0).max()
     # after the time-out the dropped handle runs the very kernels of the plain one
     assert np.abs(x0 - x2).max() < 1e-11 * np.abs(x0).max()
+
+
+def test_schur_cg_with_the_operator_in_lds_is_bit_identical_to_the_slab_stream(capfd):
+    """Blocks of at most 96 rows: k_cg_schur keeps the explicit block inverses in registers (NSX_CG_PRES) and the block's rows of
+    negative_S_tilde in LDS (NSX_CG_LRES) for the whole solve.  Same lanes, same entries per lane, same order of every sum as the
+    variant that streams the operator slabs in every iteration: the vectors are equal to the last bit.  The variant that streams the
+    block inverses too sums each row of P_b g in another grouping: equal to rounding."""
+    from navierstokes_project_nm4pde_amd.frontend import merge_ranks
+    p = Problem("cylinder", 3, 3, n_sub=128, ordering="colour")
+    assert np.diff(p.dofs.owned_p_ptr).max() <= 96
+    res = {}
+    os.environ["NSX_DEBUG"] = "1"
+    try:
+        for name, env in (("lds", {}), ("slabs", {"NSX_CG_LRES": "0"}), ("streamed", {"NSX_CG_PRES": "0"})):
+            os.environ.update(env)
+            try:
+                dev = p.device()
+                dev.set_schur_blocks(merge_ranks(p.dofs.owned_p_ptr, 96))
+                dev.set_solution(p.smooth_velocity())
+                import navierstokes_project_nm4pde_amd.nsx as nsx
+                dev.assemble(nsx.TEMAM)
+                dev.apply_boundary_values(*_bc(p, p.deltat))
+                dev.prec_initialize(0)
+                src = np.random.default_rng(8).standard_normal(p.dofs.n_dofs)
+                y, st = dev.prec_vmult(0, src, inner_rtol=1e-10)
+                t = dev.solve_time_step(0)
+                res[name] = (y, st, t, dev.solution_owned.copy(), capfd.readouterr().err)
+                dev.close()
+            finally:
+                for k in env:
+                    os.environ.pop(k, None)
+    finally:
+        os.environ.pop("NSX_DEBUG", None)
+    assert "block inverses in registers 1 (rows per lane group 6), operator in LDS 1" in res["lds"][4], res["lds"][4]
+    assert "block inverses in registers 1 (rows per lane group 6), operator in LDS 0" in res["slabs"][4]
+    assert "block inverses in registers 0" in res["streamed"][4]
+    y0, s0, t0, x0, _ = res["lds"]
+    assert s0["status"] == 0 and s0["inner_S_iterations"] > 10
+    y1, s1, t1, x1, _ = res["slabs"]
+    assert np.array_equal(y0, y1) and np.array_equal(x0, x1) and s0["inner_S_iterations"] == s1["inner_S_iterations"]
+    assert t0["outer_iterations"] == t1["outer_iterations"] and t0["inner_S_iterations"] == t1["inner_S_iterations"]
+    y2, s2, _, _, _ = res["streamed"]
+    assert abs(s2["inner_S_iterations"] - s0["inner_S_iterations"]) <= 1
+    assert np.abs(y0 - y2).max() < 1e-8 * np.abs(y0).max()
