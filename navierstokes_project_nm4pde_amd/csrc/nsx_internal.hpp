@@ -120,6 +120,10 @@ struct IluSchedule {
   int max_levels = 0;
   // packed solve stream (host/ilu_stream.hpp, k_ilu_solve_lanes): one wave per group of blocks, a lane owns a row for as many ticks
   // as the row has in-block entries; slab t = tick t of the wave
+  DevBuf<int32_t> in_cptr;      // [n_rows+1] running count of in-block entries (compact numbering of a block's factor)
+  DevBuf<int32_t> in_cpos;      // [in-block entries] compact number -> CSR position
+  DevBuf<int32_t> fac_order;    // [n_blocks] blocks by descending in-block entries (dispatch order of k_ilu_factor_lds)
+  int32_t max_block_nnz = 0;    // in-block entries of the largest block
   int64_t in_block_nnz = 0;     // in-block entries of the factor, diagonal included: what one application has to read (algorithmic bytes)
   int stream_ncomp = 0;         // the stream holds LDS byte addresses: it is built for one number of interleaved right-hand sides
   int stream_epl = 1;           // entries of its row a lane takes per tick (NSX_ILU_EPT)

@@ -122,6 +122,33 @@ void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> 
   for (int b = 0; b < nb; ++b)
     for (int i = bptr[b]; i < bptr[b + 1]; ++i)
       for (int q = g.rowptr[i]; q < g.rowptr[i + 1]; ++q) s.in_block_nnz += g.colind[q] >= bptr[b] && g.colind[q] < bptr[b + 1];
+  // ---- the in-block part of every row is one contiguous range of its (sorted) entries: [in_lo, in_hi); in_cptr: running count of
+  //      in-block entries (the compact numbering k_ilu_factor_lds stages a block with)
+  {
+    std::vector<int32_t> lo(g.n_rows), hi(g.n_rows), cptr(g.n_rows + 1, 0);
+    s.max_block_nnz = 0;
+    for (int b = 0; b < nb; ++b) {
+      for (int i = bptr[b]; i < bptr[b + 1]; ++i) {
+        const int32_t *cb = g.colind.data() + g.rowptr[i], *ce = g.colind.data() + g.rowptr[i + 1];
+        lo[i] = (int32_t)(std::lower_bound(cb, ce, bptr[b]) - g.colind.data());
+        hi[i] = (int32_t)(std::lower_bound(cb, ce, bptr[b + 1]) - g.colind.data());
+        cptr[i + 1] = cptr[i] + (hi[i] - lo[i]);
+      }
+      s.max_block_nnz = std::max(s.max_block_nnz, cptr[bptr[b + 1]] - cptr[bptr[b]]);
+    }
+    std::vector<int32_t> cpos((size_t)cptr[g.n_rows]);
+    for (int i = 0; i < g.n_rows; ++i)
+      for (int p = lo[i]; p < hi[i]; ++p) cpos[cptr[i] + (p - lo[i])] = p;
+    s.in_lo.upload(lo, h->stream);
+    s.in_hi.upload(hi, h->stream);
+    s.in_cptr.upload(cptr, h->stream);
+    s.in_cpos.upload(cpos, h->stream);
+    // blocks in order of descending work: the factorisation's workgroups are dispatched in this order, the big blocks first
+    std::vector<int32_t> order(nb);
+    for (int b = 0; b < nb; ++b) order[b] = b;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cptr[bptr[x + 1]] - cptr[bptr[x]] > cptr[bptr[y + 1]] - cptr[bptr[y]]; });
+    s.fac_order.upload(order, h->stream);
+  }
   // ---- blocks beyond what one wave (packed stream) or one workgroup can hold: merged level lists, one launch per level
   const int levelled_min = getenv("NSX_LEVELLED_MIN") ? atoi(getenv("NSX_LEVELLED_MIN")) : 4096;
   s.levelled = s.max_rows > levelled_min;
@@ -143,15 +170,6 @@ void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> 
       (pass == 0 ? s.gl_f_ptr_h : s.gl_b_ptr_h) = gptr;
       (pass == 0 ? s.gl_f_rows : s.gl_b_rows).upload(grows, h->stream);
     }
-    std::vector<int32_t> lo(g.n_rows), hi(g.n_rows);
-    for (int b = 0; b < nb; ++b)
-      for (int i = bptr[b]; i < bptr[b + 1]; ++i) {
-        const int32_t *cb = g.colind.data() + g.rowptr[i], *ce = g.colind.data() + g.rowptr[i + 1];
-        lo[i] = (int32_t)(std::lower_bound(cb, ce, bptr[b]) - g.colind.data());
-        hi[i] = (int32_t)(std::lower_bound(cb, ce, bptr[b + 1]) - g.colind.data());
-      }
-    s.in_lo.upload(lo, h->stream);
-    s.in_hi.upload(hi, h->stream);
     s.block_ptr.upload(bptr, h->stream);
     if (getenv("NSX_DEBUG"))
       fprintf(stderr, "[nsx] ilu schedule: rows %d blocks %d max_rows %d -> levelled, %d levels\n", g.n_rows, nb, s.max_rows, s.max_levels);

@@ -9,6 +9,8 @@
 // dim interleaved velocity components (the reference streams dim^2 entries, 2/3 of them explicit zeros, SURVEY A-struct).
 // All kernels are HBM/L2-bandwidth bound; reductions inside a row use wavefront shuffles (64-wide waves, sub-groups of
 // 8/16/32/64 lanes per row chosen from the average row length).
+#include <atomic>
+
 #include "nsx_internal.hpp"
 #include "nsx_ilu_lanes.hpp"
 
@@ -680,6 +682,132 @@ __global__ __launch_bounds__(ILU_WAVES * 64) void k_ilu_factor_small(const int32
   }
 }
 
+// Same factorisation with the in-block part of the whole block staged in LDS (values + 16-bit local columns in the compact
+// numbering of IluSchedule::in_cptr, row starts, diagonal positions, the level lists): the elimination of a row then makes no
+// trip through global memory at all -- k_ilu_factor_small chases ci -> diag -> lu -> ci/lu of the pivot row through L2 for every
+// L entry.  Same operations on the same entries in the same order; rows of a level are dealt to the waves, a barrier per level.
+// Dynamic LDS: ilu_factor_lds_bytes(max_rows, max_block_nnz).
+constexpr uint16_t ILU_NOPOS = 0xffffu;
+__host__ __device__ inline size_t ilu_factor_lds_bytes(int max_rows, int max_nz) {
+  const size_t nz = ((size_t)max_nz + 3) & ~(size_t)3;
+  return nz * 10 + (size_t)(max_rows + 4) * 2 * (4 + ILU_WAVES);
+}
+__global__ __launch_bounds__(ILU_WAVES * 64) void k_ilu_factor_lds(const int32_t *__restrict__ order, const int32_t *__restrict__ bptr, const int32_t *__restrict__ lvl_off,
+                                                                  const int32_t *__restrict__ lvl_ptr, const int32_t *__restrict__ lvl_rows,
+                                                                  const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                                  const int32_t *__restrict__ diag, const int32_t *__restrict__ in_lo,
+                                                                  const int32_t *__restrict__ cptr, const int32_t *__restrict__ cpos,
+                                                                  const double *__restrict__ a, double *__restrict__ lu,
+                                                                  const int32_t *__restrict__ slot_of, double *__restrict__ pk_val,
+                                                                  double *__restrict__ pk_dinv, int *__restrict__ err,
+                                                                  const int32_t *__restrict__ dinv_slot, int max_rows, int max_nz) {
+  extern __shared__ double lds_f[];
+  const int nzp = (max_nz + 3) & ~3, mr = max_rows + 4;
+  volatile double *lv = lds_f;                       // [nzp] the block's in-block entries, compact numbering
+  volatile uint16_t *lc = (uint16_t *)(lds_f + nzp);  // [nzp] block-local column
+  uint16_t *lrp = (uint16_t *)lc + nzp;              // [mr] compact row starts
+  uint16_t *ldg = lrp + mr;                          // [mr] compact position of the diagonal
+  uint16_t *llv = ldg + mr;                          // [mr] block-local rows in level order
+  uint16_t *lvp = llv + mr;                          // [mr] level starts inside llv
+  volatile uint16_t *posv = lvp + mr;                // [ILU_WAVES][mr] column -> compact position in the wave's current row
+  const int blk = order[blockIdx.x], tid = threadIdx.x, wave = tid / 64, lane = tid % 64;
+  const int r0 = bptr[blk], nb = bptr[blk + 1] - r0;
+  if (nb == 0) return;
+  const int c0 = cptr[r0];
+  const int L0 = lvl_off[blk], nlev = lvl_off[blk + 1] - L0, q0 = lvl_ptr[L0];
+  for (int q = tid; q <= nb; q += ILU_WAVES * 64) lrp[q] = (uint16_t)(cptr[r0 + q] - c0);
+  for (int q = tid; q < nb; q += ILU_WAVES * 64) {
+    ldg[q] = (uint16_t)(cptr[r0 + q] - c0 + diag[r0 + q] - in_lo[r0 + q]);
+    llv[q] = (uint16_t)(lvl_rows[q0 + q] - r0);  // the level lists of a block are contiguous and hold every row once
+  }
+  for (int q = tid; q <= nlev; q += ILU_WAVES * 64) lvp[q] = (uint16_t)(lvl_ptr[L0 + q] - q0);
+  for (int q = tid; q < ILU_WAVES * mr; q += ILU_WAVES * 64) posv[q] = ILU_NOPOS;
+  // staging and write-back run flat over the block's entries (compact number -> CSR position through cpos): every load address
+  // depends on the loop counter or on one earlier load, so the requests of several passes are in flight together
+  const int nzb = cptr[r0 + nb] - c0;
+  {
+    double *lvn = lds_f;
+    uint16_t *lcn = (uint16_t *)(lds_f + nzp);
+    const int P1 = rp[r0 + nb];
+    for (int p = rp[r0] + tid; p < P1; p += ILU_WAVES * 64) {  // entries outside the block are not part of the rank's factor
+      const int c = ci[p] - r0;
+      if (c < 0 || c >= nb) lu[p] = 0.0;
+    }
+#pragma unroll 4
+    for (int e = tid; e < nzb; e += ILU_WAVES * 64) {
+      const int p = cpos[c0 + e];
+      lvn[e] = a[p];
+      lcn[e] = (uint16_t)(ci[p] - r0);
+    }
+  }
+  __syncthreads();
+  volatile uint16_t *pos = posv + wave * mr;
+  for (int l = 0; l < nlev; ++l) {
+    const int a1 = lvp[l + 1];
+    for (int r = lvp[l] + wave; r < a1; r += ILU_WAVES) {
+      const int i = llv[r];
+      const int s0 = lrp[i], s1 = lrp[i + 1], dg = ldg[i];
+      for (int e = s0 + lane; e < s1; e += 64) pos[lc[e]] = (uint16_t)e;
+      __builtin_amdgcn_wave_barrier();
+      // L part, ascending columns (wave-uniform loop).  Everything an entry needs except its own multiplier is a constant of the
+      // pattern or belongs to a finished row -- pivot, its diagonal, this lane's entry of its scaled U row and where that lands in
+      // row i -- and is requested one entry ahead: the dependent chain per L entry is multiplier -> update, two LDS trips.
+      struct Ahead {
+        int ue, q;
+        uint16_t pc;
+        double uq, dinvk;
+      };
+      auto ahead = [&](int e) {
+        Ahead n;
+        const int k = lc[e], dk = ldg[k];
+        n.ue = lrp[k + 1];
+        n.q = dk + 1 + lane;
+        const bool has = n.q < n.ue;
+        n.pc = has ? pos[lc[has ? n.q : dk]] : ILU_NOPOS;
+        n.uq = lv[has ? n.q : dk];
+        n.dinvk = lv[dk];
+        return n;
+      };
+      Ahead cur = ahead(s0 < dg ? s0 : dg);
+      for (int e = s0; e < dg; ++e) {
+        const Ahead nxt = ahead(e + 1 < dg ? e + 1 : dg);  // (a dummy request behind the last entry: row i's own diagonal)
+        const double mult = lv[e];
+        if (lane == 0) lv[e] = mult * cur.dinvk;  // InV[jj] *= DV[j]
+        if (cur.pc != ILU_NOPOS) lv[cur.pc] -= mult * cur.uq;
+        for (int q = cur.q + 64; q < cur.ue; q += 64) {  // scaled U rows of more than 64 entries
+          const uint16_t pc = pos[lc[q]];
+          if (pc != ILU_NOPOS) lv[pc] -= mult * lv[q];
+        }
+        cur = nxt;
+      }
+      __builtin_amdgcn_wave_barrier();
+      const double d = lv[dg];
+      const double dinv = 1.0 / d;
+      if (lane == 0 && !(fabs(d) > 0.0)) __hip_atomic_store(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __builtin_amdgcn_wave_barrier();
+      for (int e = dg + lane; e < s1; e += 64) lv[e] = e == dg ? dinv : lv[e] * dinv;
+      for (int e = s0 + lane; e < s1; e += 64) pos[lc[e]] = ILU_NOPOS;
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+  }
+  {
+    const double *lvn = lds_f;
+#pragma unroll 4
+    for (int e = tid; e < nzb; e += ILU_WAVES * 64) {
+      const int p = cpos[c0 + e];
+      const double v = lvn[e];
+      lu[p] = v;
+      if (slot_of) {
+        const int sl = slot_of[p];
+        if (sl >= 0) pk_val[sl] = -v;  // the stream adds value * x[col]: it stores -L and -U/d
+      }
+    }
+    if (slot_of)
+      for (int q = tid; q < nb; q += ILU_WAVES * 64) pk_dinv[dinv_slot[r0 + q]] = lvn[ldg[q]];
+  }
+}
+
 // ---- levelled path (IluSchedule::levelled): blocks of any size, one launch per dependency level ------------------------
 // Factorisation: one wave per row of the level, same row arithmetic as k_ilu_factor (sorted-column binary search in global
 // memory); rows of earlier levels are complete because the previous launch has finished.
@@ -795,6 +923,7 @@ void ilu_factor(nsx_handle *h, const DevCsr &g, IluSchedule &s, const double *va
   {
     LaunchScope ls(h, name, 20.0 * g.nnz() + 12.0 * g.n_rows());
     static const bool small_ok = !(getenv("NSX_ILU_SMALL") && atoi(getenv("NSX_ILU_SMALL")) == 0);
+    const bool lds_ok = !(getenv("NSX_ILU_FACTOR_LDS") && atoi(getenv("NSX_ILU_FACTOR_LDS")) == 0);  // read per call: the tests switch it
     if (s.levelled) {
       for (size_t l = 0; l + 1 < s.gl_f_ptr_h.size(); ++l) {
         const int n = s.gl_f_ptr_h[l + 1] - s.gl_f_ptr_h[l];
@@ -802,6 +931,17 @@ void ilu_factor(nsx_handle *h, const DevCsr &g, IluSchedule &s, const double *va
           hipLaunchKernelGGL(k_ilu_factor_level, dim3(cdiv(n, ILU_WAVES)), dim3(ILU_WAVES * 64), 0, h->stream, n, s.gl_f_rows.p + s.gl_f_ptr_h[l],
                              s.in_lo.p, s.in_hi.p, g.rowptr.p, g.colind.p, g.diag.p, vals, lu, err);
       }
+    } else if (lds_ok && s.max_rows <= 4096 && s.max_block_nnz < 65535 && ilu_factor_lds_bytes(s.max_rows, s.max_block_nnz) <= 80 * 1024) {
+      // the whole block in LDS: at most 80 KB, so that at least two workgroups share a CU
+      const size_t lds = ilu_factor_lds_bytes(s.max_rows, s.max_block_nnz);
+      static std::atomic<size_t> lds_allowed{64 * 1024};  // per process: the attribute belongs to the function, not to a handle
+      if (lds > lds_allowed.load()) {
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_ilu_factor_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        lds_allowed.store(80 * 1024);
+      }
+      hipLaunchKernelGGL(k_ilu_factor_lds, dim3(s.n_blocks), dim3(ILU_WAVES * 64), lds, h->stream, s.fac_order.p, s.block_ptr.p, s.blk_lvl_off.p, s.fwd_lvl_ptr.p,
+                         s.fwd_rows.p, g.rowptr.p, g.colind.p, g.diag.p, s.in_lo.p, s.in_cptr.p, s.in_cpos.p, vals, lu,
+                         s.packed_ok ? s.pk_slot_of.p : nullptr, s.pk_val.p, s.pk_dinv.p, err, s.pk_dinv_slot.p, s.max_rows, (int)s.max_block_nnz);
     } else if (small_ok && s.max_rows <= ILU_DENSE_ROWS)
       hipLaunchKernelGGL(k_ilu_factor_small, dim3(s.n_blocks), dim3(ILU_WAVES * 64), 0, h->stream, s.block_ptr.p, s.blk_lvl_off.p,
                          s.fwd_lvl_ptr.p, s.fwd_rows.p, g.rowptr.p, g.colind.p, g.diag.p, vals, lu, s.packed_ok ? s.pk_slot_of.p : nullptr,

@@ -310,3 +310,27 @@ def test_schur_cg_with_the_operator_in_lds_is_bit_identical_to_the_slab_stream(c
     y2, s2, _, _, _ = res["streamed"]
     assert abs(s2["inner_S_iterations"] - s0["inner_S_iterations"]) <= 1
     assert np.abs(y0 - y2).max() < 1e-8 * np.abs(y0).max()
+
+
+def test_ilu_factorisation_in_lds_is_bit_identical_to_the_one_through_global_memory():
+    """k_ilu_factor_lds stages the in-block part of a whole rank block in LDS; NSX_ILU_FACTOR_LDS=0 is k_ilu_factor_small (dense
+    row per wave, pivot rows read from global memory).  Same operations on the same entries in the same order: equal factors
+    (F and the Schur matrix), equal packed stream (ilu_apply)."""
+    import navierstokes_project_nm4pde_amd.nsx as nsx
+    p = Problem("cylinder", 3, 2, n_sub=24, ordering="colour")
+    res = []
+    for flag in ("1", "0"):
+        os.environ["NSX_ILU_FACTOR_LDS"] = flag
+        try:
+            dev = p.device()
+            dev.set_solution(p.smooth_velocity())
+            dev.assemble(nsx.TEMAM)
+            dev.apply_boundary_values(*_bc(p, p.deltat))
+            dev.prec_initialize(0)
+            b = np.random.default_rng(2).standard_normal(p.dofs.n_u)
+            res.append((dev.ilu(0)[2], dev.ilu(1)[2], dev.ilu_apply(0, b)))
+            dev.close()
+        finally:
+            os.environ.pop("NSX_ILU_FACTOR_LDS", None)
+    for x, y in zip(*res):
+        assert np.abs(x).max() > 0 and np.array_equal(x, y)
