@@ -64,7 +64,9 @@ def test_full_size_operator_identities_and_solve(big):
     assert st["status"] == 0 and 5 <= st["outer_iterations"] <= 200
     x = dev.solution_owned
     r = b - dev.system_vmult(x)
-    assert np.linalg.norm(r) < 2e-2 * np.linalg.norm(b)                    # stopping test is on the preconditioned residual (1e-4 abs)
+    # the stopping test is on the preconditioned residual (1e-4 absolute, NS3D.cpp:550) of a system whose right-hand side is
+    # M u / dt ~ 1e4 |u|: the true residual ends around 7e-8 |b| here (measured); 1e-5 leaves two orders for other roundings
+    assert np.linalg.norm(r) < 1e-5 * np.linalg.norm(b)
     assert np.abs(x[bd] - bv).max() < 1e-5 * max(1.0, np.abs(bv).max())
     assert np.array_equal(dev.solution, x)                                 # solution = solution_owned
 
