@@ -661,6 +661,8 @@ __global__ __launch_bounds__(256) void k_mgs_one(int n, int split, int gap, doub
   const int nwg = gridDim.x, wg = blockIdx.x, T = nwg * 256, t = wg * 256 + threadIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (threadIdx.x == 0) s_err = 0;
+  [[maybe_unused]] int n_stamp = 0;  // development only (tools/mgs_bench.hip): the stamps are empty without NSX_MGS_TRACE
+  MGS_STAMP();  // start
   unsigned long long *total = box + (size_t)MGS_ONE_VALS * MGS_MAX_WG, *total_next = box_next + (size_t)MGS_ONE_VALS * MGS_MAX_WG;
   for (int q = t; q < reset_words; q += T) box_next[q] = GX_EMPTY;
   if (wg == 0 && threadIdx.x < MGS_ONE_VALS) total_next[threadIdx.x] = GX_EMPTY;
@@ -726,6 +728,7 @@ __global__ __launch_bounds__(256) void k_mgs_one(int n, int split, int gap, doub
       wave_post(dim + j_keep + i, ag);
     }
   __syncthreads();
+  MGS_STAMP();  // loads arrived, local sums done
   // ---- hop 1: mailboxes; value v is summed by workgroup v % nwg
   int lerr = 0;
   for (int v = threadIdx.x; v < nvals; v += 256)
@@ -741,12 +744,14 @@ __global__ __launch_bounds__(256) void k_mgs_one(int n, int split, int gap, doub
     if (threadIdx.x == 0 && !s_err) gx_post(total + v, (sh[0][0] + sh[1][0]) + (sh[2][0] + sh[3][0]));  // a total built on a timed-out mailbox never goes out
     __syncthreads();
   }
+  MGS_STAMP();  // posted, and (reducers) totals out
   // ---- hop 2: everybody picks up the totals
   for (int v = threadIdx.x; v < nvals; v += 256) {
     tot[v] = gx_wait_value(total + v, &lerr);
     if (lerr) s_err = 1;
   }
   __syncthreads();
+  MGS_STAMP();  // totals picked up
   bool dead = s_err != 0;
   if (!dead) {
     // Gram matrix of the basis: older rows from memory, the new row from this exchange; then h by forward substitution and the
@@ -779,6 +784,7 @@ __global__ __launch_bounds__(256) void k_mgs_one(int n, int split, int gap, doub
       if (lane == 0) s_norm2 = tot[2 * dim] + quad;
     }
     __syncthreads();
+    MGS_STAMP();  // coefficients solved
     // w += (-h_j) v_j, j ascending: the streamed (older) vectors first, then the kept block
     for (int j = 0; j < j_keep; ++j) {
       const double *__restrict__ vp = V.v[j];
@@ -864,9 +870,11 @@ __global__ __launch_bounds__(256) void k_mgs_one(int n, int split, int gap, doub
     if (threadIdx.x == 0) __hip_atomic_store(pub_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   if (threadIdx.x == 0) tail[wg] = seq;  // this workgroup commits its part of w
+  MGS_STAMP();  // update done
 #pragma unroll
   for (int k = 0; k < E; ++k)
     if (idx[k] >= 0) w[idx[k]] = wv[k];
+  MGS_STAMP();  // stores issued
 }
 
 static const void *mgs_one_fn(int e) { return e <= 8 ? (const void *)k_mgs_one<8, 10> : (const void *)k_mgs_one<10, 8>; }
