@@ -150,6 +150,7 @@ struct IluSchedule {
   bool levelled = false;
   std::vector<int32_t> gl_f_ptr_h, gl_b_ptr_h;  // [levels+1] offsets into gl_f_rows / gl_b_rows
   DevBuf<int32_t> gl_f_rows, gl_b_rows, in_lo, in_hi;
+  DevBuf<int32_t> gl_f_rec, gl_b_rec;  // [4 * rows] per row in level order: row, first entry, end of entries, diagonal (k_ilu_solve_level)
 };
 
 // Ghost exchange plan of one scalar space (the Epetra_Import of every vmult): neighbours in ascending rank order,

@@ -124,8 +124,9 @@ void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> 
       for (int q = g.rowptr[i]; q < g.rowptr[i + 1]; ++q) s.in_block_nnz += g.colind[q] >= bptr[b] && g.colind[q] < bptr[b + 1];
   // ---- the in-block part of every row is one contiguous range of its (sorted) entries: [in_lo, in_hi); in_cptr: running count of
   //      in-block entries (the compact numbering k_ilu_factor_lds stages a block with)
+  std::vector<int32_t> lo(g.n_rows), hi(g.n_rows);
   {
-    std::vector<int32_t> lo(g.n_rows), hi(g.n_rows), cptr(g.n_rows + 1, 0);
+    std::vector<int32_t> cptr(g.n_rows + 1, 0);
     s.max_block_nnz = 0;
     for (int b = 0; b < nb; ++b) {
       for (int i = bptr[b]; i < bptr[b + 1]; ++i) {
@@ -169,6 +170,17 @@ void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> 
           for (int q = ptr[l]; q < ptr[l + 1]; ++q) grows[fill[l - off[b]]++] = rows[q];
       (pass == 0 ? s.gl_f_ptr_h : s.gl_b_ptr_h) = gptr;
       (pass == 0 ? s.gl_f_rows : s.gl_b_rows).upload(grows, h->stream);
+      // one record per row in level order -- {row, first entry, end of entries, diagonal} of the sweep's triangle -- so that a level
+      // kernel learns everything about its row in ONE coalesced load (it used to chase rows -> diag, in_lo/in_hi -> entries)
+      std::vector<int32_t> rec(4 * grows.size());
+      for (size_t r = 0; r < grows.size(); ++r) {
+        const int i = grows[r], d = find_in_row(g, i, i);
+        rec[4 * r + 0] = i;
+        rec[4 * r + 1] = pass == 0 ? lo[i] : d + 1;
+        rec[4 * r + 2] = pass == 0 ? d : hi[i];
+        rec[4 * r + 3] = d;
+      }
+      (pass == 0 ? s.gl_f_rec : s.gl_b_rec).upload(rec, h->stream);
     }
     s.block_ptr.upload(bptr, h->stream);
     if (getenv("NSX_DEBUG"))

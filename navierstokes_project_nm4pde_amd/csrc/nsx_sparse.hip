@@ -861,14 +861,21 @@ __global__ __launch_bounds__(ILU_WAVES * 64) void k_ilu_factor_level(int n_lvl_r
 // forward:  x_i -= sum_{j<i in block} L_ij x_j ;  backward: x_i = x_i / d_i - sum_{j>i in block} (U_ij/d_i) x_j
 // (the D^-1 scaling of Ifpack's ApplyInverse is folded into the backward visit of each row: its x_j are final by then)
 template <int NCOMP, int LW, bool FWD>
-__global__ __launch_bounds__(256) void k_ilu_solve_level(int n_lvl_rows, const int32_t *__restrict__ rows, const int32_t *__restrict__ in_lo,
-                                                         const int32_t *__restrict__ in_hi, const int32_t *__restrict__ ci,
-                                                         const int32_t *__restrict__ diag, const double *__restrict__ lu, double *x) {
+__global__ __launch_bounds__(256) void k_ilu_solve_level(int n_lvl_rows, const int4 *__restrict__ rec, const int32_t *__restrict__ ci,
+                                                         const double *__restrict__ lu, double *x) {
   const int r = (blockIdx.x * 256 + threadIdx.x) / LW, lane = threadIdx.x % LW;
   if (r >= n_lvl_rows) return;
-  const int i = rows[r];
-  const int d = diag[i];
-  const int pb = FWD ? in_lo[i] : d + 1, pe = FWD ? d : in_hi[i];
+  const int4 q = rec[r];  // row, first entry, end of entries, diagonal: one trip (the records of a level are contiguous)
+  const int i = q.x, pb = q.y, pe = q.z;
+  // requested with the entries, not behind the reduction: the row's own value and (backward) its 1 / d
+  double xi0[NCOMP];
+  double *xi = x + (size_t)i * NCOMP;
+  double dinv = 1.0;
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) xi0[c] = xi[c];
+    if (!FWD) dinv = lu[q.w];
+  }
   double acc[NCOMP];
 #pragma unroll
   for (int c = 0; c < NCOMP; ++c) acc[c] = 0.0;
@@ -881,10 +888,8 @@ __global__ __launch_bounds__(256) void k_ilu_solve_level(int n_lvl_rows, const i
 #pragma unroll
   for (int c = 0; c < NCOMP; ++c) acc[c] = lane_group_sum<LW>(acc[c]);
   if (lane == 0) {
-    double *xi = x + (size_t)i * NCOMP;
-    const double dinv = FWD ? 1.0 : lu[d];
 #pragma unroll
-    for (int c = 0; c < NCOMP; ++c) xi[c] = FWD ? xi[c] - acc[c] : xi[c] * dinv - acc[c];
+    for (int c = 0; c < NCOMP; ++c) xi[c] = FWD ? xi0[c] - acc[c] : xi0[c] * dinv - acc[c];
   }
 }
 
@@ -897,13 +902,13 @@ static void ilu_solve_levelled(nsx_handle *h, const DevCsr &g, const IluSchedule
     const int n = s.gl_f_ptr_h[l + 1] - s.gl_f_ptr_h[l];
     if (n > 0)
       hipLaunchKernelGGL((k_ilu_solve_level<NCOMP, LW, true>), dim3(cdiv((int64_t)n * LW, 256)), dim3(256), 0, h->stream, n,
-                         s.gl_f_rows.p + s.gl_f_ptr_h[l], s.in_lo.p, s.in_hi.p, g.colind.p, g.diag.p, lu, x);
+                         reinterpret_cast<const int4 *>(s.gl_f_rec.p) + s.gl_f_ptr_h[l], g.colind.p, lu, x);
   }
   for (int l = 0; l < nbk; ++l) {
     const int n = s.gl_b_ptr_h[l + 1] - s.gl_b_ptr_h[l];
     if (n > 0)
       hipLaunchKernelGGL((k_ilu_solve_level<NCOMP, LW, false>), dim3(cdiv((int64_t)n * LW, 256)), dim3(256), 0, h->stream, n,
-                         s.gl_b_rows.p + s.gl_b_ptr_h[l], s.in_lo.p, s.in_hi.p, g.colind.p, g.diag.p, lu, x);
+                         reinterpret_cast<const int4 *>(s.gl_b_rec.p) + s.gl_b_ptr_h[l], g.colind.p, lu, x);
   }
 }
 
