@@ -20,6 +20,15 @@ device: $(DEV_SO)
 $(HOST_SO): $(PKG)/host/frontend.cpp $(PKG)/host/graph.hpp $(PKG)/host/ilu_stream.hpp include/nsx_host.h
 	$(CXX) $(CXXFLAGS) -shared -o $@ $(PKG)/host/frontend.cpp
 
+# host front-end + schedule builders under AddressSanitizer / UBSan (CPU only; GPU sanitizers are not available on the pool):
+#   make host-asan   builds and runs the front-end and ILU-stream tests against the instrumented library, then restores the plain one
+host-asan:
+	$(CXX) -O1 -g -std=c++17 -fPIC -fsanitize=address,undefined -fno-omit-frame-pointer -shared -o $(HOST_SO) $(PKG)/host/frontend.cpp
+	ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \
+	LD_PRELOAD=$$($(CC) -print-file-name=libasan.so):$$($(CC) -print-file-name=libubsan.so) \
+	python3 -m pytest tests/test_frontend.py tests/test_ilu_stream.py -x -q -m "not gpu" -p no:cacheprovider; rc=$$?; \
+	$(CXX) $(CXXFLAGS) -shared -o $(HOST_SO) $(PKG)/host/frontend.cpp; exit $$rc
+
 $(ORACLE_SO): oracle/nsx_oracle.c oracle/nsx_oracle.h
 	$(CC) $(CFLAGS) -shared -o $@ oracle/nsx_oracle.c -lm
 # the same restatement with its rank-parallel loops on OpenMP threads: bench.py's all-cores CPU baseline
@@ -43,4 +52,4 @@ $(PKG)/host/convergence: $(PKG)/host/main_convergence.cpp $(PKG)/host/Convergenc
 
 clean:
 	rm -f $(HOST_SO) $(DEV_SO) $(ORACLE_SO) $(ORACLE_MT_SO) $(MIRROR_BIN)
-.PHONY: all host oracle device mirror clean
+.PHONY: host-asan all host oracle device mirror clean
