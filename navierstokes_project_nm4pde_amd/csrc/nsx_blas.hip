@@ -667,6 +667,19 @@ __global__ __launch_bounds__(256) void k_mgs_one(int n, int split, int gap, doub
   for (int q = t; q < reset_words; q += T) box_next[q] = GX_EMPTY;
   if (wg == 0 && threadIdx.x < MGS_ONE_VALS) total_next[threadIdx.x] = GX_EMPTY;
   const int nvals = 2 * dim + 1;  // r_j at j, g_j at dim + j, |w|^2 at 2 dim
+  // the older rows of the Gram matrix (written by the earlier sweeps of this cycle) are requested first and parked in registers:
+  // read behind the exchange they were a trip through memory on the critical path of every workgroup
+  // (only where the registers are there: the E = 10 instantiation would lose its second wave per SIMD, and with it the resident grid)
+  constexpr bool PRE = E <= 8;
+  constexpr int GPRE = PRE ? (MGS_STEPS * MGS_STEPS + 255) / 256 : 1;
+  double gpre[GPRE];
+  if constexpr (PRE) {
+#pragma unroll
+    for (int k = 0; k < GPRE; ++k) {
+      const int q = threadIdx.x + 256 * k, r_ = q / MGS_STEPS, c_ = q % MGS_STEPS;
+      gpre[k] = (r_ < dim - 1 && c_ <= r_) ? gram[r_ * 32 + c_] : 0.0;
+    }
+  }
   double wv[E], vb[DMAX][E];
   int idx[E];
 #pragma unroll
@@ -727,6 +740,13 @@ __global__ __launch_bounds__(256) void k_mgs_one(int n, int split, int gap, doub
       wave_post(j_keep + i, ar);
       wave_post(dim + j_keep + i, ag);
     }
+  if constexpr (PRE) {
+#pragma unroll
+    for (int k = 0; k < GPRE; ++k) {
+      const int q = threadIdx.x + 256 * k, r_ = q / MGS_STEPS, c_ = q % MGS_STEPS;
+      if (r_ < dim - 1 && c_ <= r_) G[r_][c_] = gpre[k];
+    }
+  }
   __syncthreads();
   MGS_STAMP();  // loads arrived, local sums done
   // ---- hop 1: mailboxes; value v is summed by workgroup v % nwg
@@ -753,12 +773,17 @@ __global__ __launch_bounds__(256) void k_mgs_one(int n, int split, int gap, doub
   __syncthreads();
   MGS_STAMP();  // totals picked up
   bool dead = s_err != 0;
+  double xo[E];  // entries of the next streamed (older) vector of the update below
+#pragma unroll
+  for (int k = 0; k < E; ++k) xo[k] = (!dead && j_keep > 0 && idx[k] >= 0) ? ld_stream<1>(V.v[0] + idx[k]) : 0.0;
   if (!dead) {
-    // Gram matrix of the basis: older rows from memory, the new row from this exchange; then h by forward substitution and the
+    // Gram matrix of the basis: older rows parked in G before the exchange, the new row from this exchange; then h by forward substitution and the
     // norm after the sweep, one wave, lane j = link j
-    for (int q = threadIdx.x; q < (dim - 1) * MGS_STEPS; q += 256) {
-      const int r_ = q / MGS_STEPS, c_ = q % MGS_STEPS;
-      if (c_ <= r_) G[r_][c_] = gram[r_ * 32 + c_];
+    if constexpr (!PRE) {
+      for (int q = threadIdx.x; q < (dim - 1) * MGS_STEPS; q += 256) {
+        const int r_ = q / MGS_STEPS, c_ = q % MGS_STEPS;
+        if (c_ <= r_) G[r_][c_] = gram[r_ * 32 + c_];
+      }
     }
     if ((int)threadIdx.x < dim) G[dim - 1][threadIdx.x] = tot[dim + threadIdx.x];
     __syncthreads();
@@ -785,13 +810,20 @@ __global__ __launch_bounds__(256) void k_mgs_one(int n, int split, int gap, doub
     }
     __syncthreads();
     MGS_STAMP();  // coefficients solved
-    // w += (-h_j) v_j, j ascending: the streamed (older) vectors first, then the kept block
+    // w += (-h_j) v_j, j ascending: the streamed (older) vectors first, then the kept block.  The entries of vector j + 1 are
+    // requested before those of vector j are used (one vector ahead; the first one in front of the coefficient solve): taken one
+    // after the other every older vector cost a full trip through memory, 4 us each at dim 14 (profiles/r03_mgs_one_timeline.txt).
+    // Same operations on the same operands in the same order.
     for (int j = 0; j < j_keep; ++j) {
-      const double *__restrict__ vp = V.v[j];
+      double xn[E];
+#pragma unroll
+      for (int k = 0; k < E; ++k) xn[k] = (j + 1 < j_keep && idx[k] >= 0) ? ld_stream<1>(V.v[j + 1] + idx[k]) : 0.0;
       const double alpha = -1.0 * hc[j];
 #pragma unroll
       for (int k = 0; k < E; ++k)
-        if (idx[k] >= 0) wv[k] += alpha * ld_stream<1>(vp + idx[k]);
+        if (idx[k] >= 0) wv[k] += alpha * xo[k];
+#pragma unroll
+      for (int k = 0; k < E; ++k) xo[k] = xn[k];
     }
 #pragma unroll
     for (int i = 0; i < DMAX; ++i)
