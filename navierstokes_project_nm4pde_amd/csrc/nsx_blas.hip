@@ -789,11 +789,17 @@ __global__ __launch_bounds__(256) void k_mgs_one(int n, int split, int gap, doub
     __syncthreads();
     if (wave == 0) {
       double hj = 0.0;
+      const int col = lane < dim ? lane : 0;
+      double g_cur = G[0][col], t_cur = tot[0];  // the LDS operands of link j + 1 are requested while link j is summed
       for (int j = 0; j < dim; ++j) {
+        const int jn = j + 1 < dim ? j + 1 : j;
+        const double g_next = G[jn][col], t_next = tot[jn];
         // s = sum_{i<j} G_ji h_i over the lanes i < j
-        double part = (lane < j) ? G[j][lane] * hj : 0.0;
+        double part = (lane < j) ? g_cur * hj : 0.0;
         part = gx_wave_sum(part);
-        if (lane == j) hj = tot[j] - part;
+        if (lane == j) hj = t_cur - part;
+        g_cur = g_next;
+        t_cur = t_next;
       }
       if (lane < dim) hc[lane] = hj;
       // |w'|^2 = |w|^2 - 2 h.r + h^T G h   (G symmetric: row lane against all columns)
