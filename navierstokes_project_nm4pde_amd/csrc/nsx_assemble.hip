@@ -177,11 +177,24 @@ __global__ __launch_bounds__(256) void k_gather(int64_t n_out, const int32_t *__
   double s[NCOMP];
 #pragma unroll
   for (int c = 0; c < NCOMP; ++c) s[c] = 0.0;
+  // four contributions per pass: their offsets are requested together, then their values, then they are added in the order of the
+  // list (one at a time every contribution was two trips through memory behind the one before it)
   const int k1 = ptr[e + 1];
-  for (int k = ptr[e]; k < k1; ++k) {
-    const int64_t o = src[k];
+  for (int k0 = ptr[e]; k0 < k1; k0 += 4) {
+    int64_t o[4];
+    double v[4][NCOMP];
 #pragma unroll
-    for (int c = 0; c < NCOMP; ++c) s[c] += buf[o + c * comp_stride];
+    for (int u = 0; u < 4; ++u) o[u] = k0 + u < k1 ? (int64_t)src[k0 + u] : -1;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int c = 0; c < NCOMP; ++c) v[u][c] = o[u] >= 0 ? buf[o[u] + c * comp_stride] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (o[u] >= 0) {
+#pragma unroll
+        for (int c = 0; c < NCOMP; ++c) s[c] += v[u][c];
+      }
   }
 #pragma unroll
   for (int c = 0; c < NCOMP; ++c) {
