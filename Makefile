@@ -17,7 +17,7 @@ host: $(HOST_SO)
 oracle: $(ORACLE_SO) $(ORACLE_MT_SO)
 device: $(DEV_SO)
 
-$(HOST_SO): $(PKG)/host/frontend.cpp $(PKG)/host/graph.hpp $(PKG)/host/ilu_stream.hpp include/nsx_host.h
+$(HOST_SO): $(PKG)/host/frontend.cpp $(PKG)/host/graph.hpp $(PKG)/host/ilu_stream.hpp $(PKG)/host/layout.hpp include/nsx_host.h
 	$(CXX) $(CXXFLAGS) -shared -o $@ $(PKG)/host/frontend.cpp
 
 # host front-end + schedule builders under AddressSanitizer / UBSan (CPU only; GPU sanitizers are not available on the pool):
@@ -36,7 +36,7 @@ $(ORACLE_MT_SO): oracle/nsx_oracle.c oracle/nsx_oracle.h
 	$(CC) $(CFLAGS) -fopenmp -shared -o $@ oracle/nsx_oracle.c -lm
 
 DEV_SRC := $(wildcard $(PKG)/csrc/*.hip)
-DEV_HDR := $(wildcard $(PKG)/csrc/*.hpp) include/nsx.h $(PKG)/host/graph.hpp $(PKG)/host/ilu_stream.hpp
+DEV_HDR := $(wildcard $(PKG)/csrc/*.hpp) include/nsx.h $(PKG)/host/graph.hpp $(PKG)/host/ilu_stream.hpp $(PKG)/host/layout.hpp
 $(DEV_SO): $(DEV_SRC) $(DEV_HDR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(DEV_SRC) -L/opt/rocm/lib -lrccl
 

@@ -103,6 +103,30 @@ int nsx_set_ranks(nsx_handle *h, int n_ranks, const int32_t *u_ptr, const int32_
 /* Optional: coarser blocks for the Schur-complement ILU (unions of consecutive ranks); default = the ranks. */
 int nsx_set_schur_blocks(nsx_handle *h, int n_blocks, const int32_t *p_ptr);
 
+/* The numbering libnsx works in BEHIND this boundary.  The reference numbers its DoFs with distribute_dofs +
+ * DoFRenumbering::component_wise on a METIS partition into mpi_size parts (reference NavierStokes3D.cpp:16-19,58-69) and a caller
+ * hands exactly that over (nsx_set_mesh, nsx_set_ranks).  The triangular solves of the per-rank ILU(0) want thousands of small,
+ * spatially compact rank blocks with a shallow dependency graph inside each; with this call libnsx builds them itself:
+ * inside the node range of EVERY rank of the caller the cells are bisected (coordinates of their centroids) into virtual ranks --
+ * n_virtual_ranks over the whole handle, dealt to the caller's ranks in proportion to their nodes --, a node belongs to the lowest
+ * virtual rank touching it (deal.II's rule), nodes are numbered virtual rank by virtual rank in first-touch order (cell by cell,
+ * vertices then lines) and, for NSX_ORDER_COLOUR, sorted by a greedy colouring of the rank's P2 graph (NSX_ORDER_COLOUR_ALL: the
+ * pressure nodes as well, on the graph of the Schur complement).  schur_max_rows > 0 merges consecutive virtual ranks into Schur
+ * ILU blocks of at most that many pressure rows (never across a rank of the caller); 0: one block per virtual rank.
+ * What the library then computes is what the reference computes on n_virtual_ranks MPI ranks with that numbering (per-rank ILU(0),
+ * per-rank diagonal of apply_boundary_values).  NOTHING changes at the boundary: every vector, dof list, graph and value array that
+ * crosses it stays in the caller's numbering (permuted on the device on the way in and out).
+ * Call order: any time before nsx_assemble -- before nsx_set_mesh (one set-up pass) or after it and after nsx_set_ranks (the set-up
+ * products are rebuilt; state vectors are reset).  nsx_set_ranks afterwards lays the nodes out again inside the new ranges;
+ * nsx_set_schur_blocks is refused while a layout is in force.  n_virtual_ranks = 0 switches the layout off. */
+enum { NSX_ORDER_FIRST_TOUCH = 0, NSX_ORDER_COLOUR = 1, NSX_ORDER_COLOUR_ALL = 2 };
+int nsx_set_internal_layout(nsx_handle *h, int n_virtual_ranks, int order, int schur_max_rows);
+/* info = {layout in force (0/1), ranks the ILU(0) of system(0,0) runs on, Schur ILU blocks, colours of the P2 nodes, colours of the P1 nodes} */
+int nsx_layout_info(nsx_handle *h, int info[5]);
+/* The layout itself, for tests and tools (any pointer may be NULL): node_perm[i] / pnode_perm[i] = internal (global) number of the
+ * i-th P2 / P1 node this handle owns, u_ptr / p_ptr [info[1] + 1] the internal node ranges of the ranks, schur_ptr [info[2] + 1]. */
+int nsx_layout_get(nsx_handle *h, int32_t *node_perm, int32_t *pnode_perm, int32_t *u_ptr, int32_t *p_ptr, int32_t *schur_ptr);
+
 /* ---- state ---- */
 /* `solution` (ghosted) and `solution_owned` (reference NavierStokes3D.hpp:245-248), length n_u + n_p. */
 int nsx_set_solution(nsx_handle *h, const double *solution_owned);  /* also does solution = solution_owned (NavierStokes3D.cpp:696-697) */
@@ -197,8 +221,9 @@ typedef int (*nsx_exchange_fn)(void *ctx, int n, const int *ranks, const double 
 int nsx_comm_init_callbacks(nsx_handle *h, int rank, int world, nsx_allreduce_fn allreduce, nsx_exchange_fn exchange, void *ctx);
 /* Collectives issued by this handle since the communicator was set: counts[0] all-reduces (the MPI_Allreduce behind Epetra's
  * Dot / Norm2, reference Preconditioners.hpp:157,179,371,388,403 and every SolverGMRES / SolverCG iteration), counts[1] ghost
- * exchanges (the Epetra_Import of every vmult).  The orthogonalisation of a Krylov vector costs two all-reduces (csrc/nsx_blas.hip,
- * mgs_lowsync) where the reference pays one per link of the add_and_dot chain. */
+ * exchanges (the Epetra_Import of every vmult).  The orthogonalisation of a Krylov vector costs ONE all-reduce (csrc/nsx_blas.hip,
+ * mgs_lowsync; a second one only when the sweep removes more than 99 % of the vector's norm) where the reference pays one per link
+ * of the add_and_dot chain. */
 int nsx_comm_counters(const nsx_handle *h, long long counts[2]);
 /* Distributed mesh, replaces nsx_set_mesh for world > 1.  cell_dofs keep the GLOBAL deal.II numbering; gpu_u_ptr /
  * gpu_p_ptr [world+1] are the P2 / P1 node ranges owned by each rank (locally_owned_dofs per block, reference

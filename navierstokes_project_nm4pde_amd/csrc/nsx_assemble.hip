@@ -383,7 +383,8 @@ void run_dirichlet(nsx_handle *h, int n_in, const int32_t *dofs_in, const double
     if (dofs_in[k] < 0 || dofs_in[k] >= h->n_u_glob) NSX_THROW(NSX_ERR_UNSUPPORTED, "only velocity dofs can be constrained (dof %d)", dofs_in[k]);
     if (k > 0 && dofs_in[k] <= dofs_in[k - 1]) NSX_THROW(NSX_ERR_ARG, "boundary map must be sorted by dof (std::map order)");
     if (dofs_in[k] >= lo && dofs_in[k] < hi) {
-      dofs.push_back(dofs_in[k] - lo);
+      const int32_t l = dofs_in[k] - lo;  // caller-local dof -> the node's place in the internal layout, same component
+      dofs.push_back(dim * node_to_internal(h, l / dim) + l % dim);
       vals.push_back(vals_in[k]);
     }
   }
@@ -458,9 +459,13 @@ int nsx_add_rhs(nsx_handle *h, int n, const int32_t *dofs, const double *vals) {
     for (int k = 0; k < n; ++k) {
       const int32_t g = dofs[k];
       if (g < h->n_u_glob) {
-        if (g >= h->dim * h->goff_u && g < h->dim * h->goff_u + h->n_u) { ld.push_back(g - h->dim * h->goff_u); lv.push_back(vals[k]); }
+        if (g >= h->dim * h->goff_u && g < h->dim * h->goff_u + h->n_u) {
+          const int32_t l = g - h->dim * h->goff_u;
+          ld.push_back(h->dim * nsx::node_to_internal(h, l / h->dim) + l % h->dim);
+          lv.push_back(vals[k]);
+        }
       } else if (g - h->n_u_glob >= h->goff_p && g - h->n_u_glob < h->goff_p + h->n_p) {
-        ld.push_back(h->off_p + g - h->n_u_glob - h->goff_p);
+        ld.push_back(h->off_p + nsx::pnode_to_internal(h, g - h->n_u_glob - h->goff_p));
         lv.push_back(vals[k]);
       }
     }

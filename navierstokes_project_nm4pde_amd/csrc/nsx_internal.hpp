@@ -158,7 +158,8 @@ struct IluSchedule {
 struct HaloPlan {
   std::vector<int> nbr;
   std::vector<int32_t> send_ptr, recv_ptr;  // [n_nbr+1], node units
-  DevBuf<int32_t> send_idx;                 // local (owned) node ids to pack
+  std::vector<int32_t> send_idx_in;         // owned nodes to pack, caller-local ids (the internal layout maps them)
+  DevBuf<int32_t> send_idx;                 // local (owned) node ids to pack, internal numbering
   DevBuf<double> sendbuf;
   std::vector<double> h_send, h_recv;       // host staging for the callback backend
   int n_own = 0;                            // ghosts start at node n_own
@@ -232,7 +233,20 @@ struct nsx_handle {
   nsx::DevBuf<double> tab_N2, tab_dN2, tab_N1, tab_w, tab_N2T, tab_dN2T;  // T: [a][q] / [b][q][k]
   nsx::DevBuf<int32_t> cell_n2, cell_n1;  // SoA [a][cell]
   nsx::DevBuf<double> geo;                // SoA [(dim*dim+1)][cell]
-  std::vector<int32_t> cell_n2_h, cell_n1_h;
+  std::vector<int32_t> cell_n2_h, cell_n1_h;  // scalar connectivity in the INTERNAL numbering (what every product below is built from)
+  // ---- internal layout (nsx_set_internal_layout): the caller keeps its own numbering and rank count, libnsx renumbers the owned
+  //      nodes behind the boundary (virtual ranks + colour order, host/layout.hpp); perm: caller-local owned node -> internal node
+  std::vector<int32_t> cell_n2_in, cell_n1_in;   // connectivity as handed over (caller-local ids: owned < N2 <= ghosts)
+  std::vector<double> cell_coords_in;            // [n_cells][dim+1][dim]: a new layout reruns the set-up products
+  std::vector<int32_t> in_rank_u_h, in_rank_p_h, in_sblk_h;  // the caller's rank / Schur block tables (local node ids)
+  int layout_req_ranks = 0, layout_req_order = 0, layout_req_schur = 0;  // the request (0 ranks: none; may precede nsx_set_mesh)
+  bool layout_on = false;
+  int layout_colours = 0, layout_colours_p = 0;
+  std::vector<int32_t> perm2_h, perm1_h, iperm2_h, iperm1_h;
+  nsx::DevBuf<int32_t> perm2_d, perm1_d;
+  nsx::DevBuf<double> io_stage;                  // block vector in the caller's order on its way in / out
+  nsx::Csr caller_graph[2];                      // scalar velocity / Schur graph in the caller's numbering (exports), built on demand
+  std::vector<int32_t> caller_pos[2];            // ... and for each of its entries the position in the internal CSR
   // ---- graphs and values
   nsx::DevCsr gA, gG, gB, gS, gPM;
   nsx::SpmvBlocked blkA;
@@ -335,6 +349,13 @@ inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> &block_ptr, IluSchedule &s, int blocks_per_wave, bool allow_dense = false,
                         int ncomp = 1);
 void build_schur_graph(nsx_handle *h);
+// host vectors of the C-ABI are in the CALLER's numbering (global [n_u_glob | n_p_glob]); device block vectors in the internal one
+void vec_from_caller(nsx_handle *h, double *dev, const double *host, bool with_ghosts);  // owned (+ ghost) entries of a block vector
+void vec_to_caller(nsx_handle *h, const double *dev, double *host);                      // owned entries only
+void part_from_caller(nsx_handle *h, int which, double *dev, const double *host);        // one space, single-process handles: 0 velocity [n_u], 1 pressure [n_p]
+void part_to_caller(nsx_handle *h, int which, const double *dev, double *host);
+inline int32_t node_to_internal(const nsx_handle *h, int32_t local_node) { return h->layout_on ? h->perm2_h[local_node] : local_node; }
+inline int32_t pnode_to_internal(const nsx_handle *h, int32_t local_node) { return h->layout_on ? h->perm1_h[local_node] : local_node; }
 void ensure_schedules(nsx_handle *h);  // (re)build the ILU schedules if the rank / Schur block tables changed
 
 // assembly (nsx_assemble.hip)

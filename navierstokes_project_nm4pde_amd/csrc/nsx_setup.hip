@@ -8,6 +8,7 @@
 
 #include "nsx_internal.hpp"
 #include "../host/ilu_stream.hpp"
+#include "../host/layout.hpp"
 
 using namespace nsx;
 
@@ -353,9 +354,9 @@ void build_schur_graph(nsx_handle *h) {
 }
 
 static void default_ranks(nsx_handle *h) {
-  h->rank_u_h = {0, h->N2};
-  h->rank_p_h = {0, h->NP};
-  h->sblk_h.clear();
+  h->in_rank_u_h = {0, h->N2};
+  h->in_rank_p_h = {0, h->NP};
+  h->in_sblk_h.clear();
 }
 
 // The rank tables changed: the Dirichlet scan needs them at once, the ILU schedules (seconds of host work at 1 M DoF) are
@@ -382,6 +383,95 @@ void ensure_schedules(nsx_handle *h) {
   setup_ilu_schedule(h, h->gS.host, sb, h->schedS, bpwS, denseS, 1);
   build_cg_plan(h);
   h->sched_dirty = false;
+}
+
+
+// caller order <-> internal order of one space: entry (node, c) of the caller sits at (perm[node], c) inside libnsx
+__global__ void k_perm_vec(int n, int ncomp, const int32_t *__restrict__ perm, double *caller, double *internal, int to_internal) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int node = i / ncomp, c = i - node * ncomp;
+  const int64_t j = (int64_t)perm[node] * ncomp + c;
+  if (to_internal) internal[j] = caller[i];
+  else caller[i] = internal[j];
+}
+
+static void perm_launch(nsx_handle *h, int which, double *caller_dev, double *internal_dev, bool to_internal) {
+  const int ncomp = which == 0 ? h->dim : 1, n = which == 0 ? h->n_u : h->n_p;
+  if (n) hipLaunchKernelGGL(k_perm_vec, dim3(cdiv(n, 256)), dim3(256), 0, h->stream, n, ncomp, (which == 0 ? h->perm2_d : h->perm1_d).p, caller_dev, internal_dev, to_internal ? 1 : 0);
+}
+
+void part_from_caller(nsx_handle *h, int which, double *dev, const double *host) {
+  const int n = which == 0 ? h->n_u : h->n_p;
+  if (!h->layout_on) {
+    HIP_CHECK(hipMemcpyAsync(dev, host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  } else {
+    h->io_stage.alloc((size_t)h->n_u + h->n_p);
+    HIP_CHECK(hipMemcpyAsync(h->io_stage.p, host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    perm_launch(h, which, h->io_stage.p, dev, true);
+  }
+  HIP_CHECK(hipStreamSynchronize(h->stream));  // host arrays are borrowed for the call only
+}
+
+void part_to_caller(nsx_handle *h, int which, const double *dev, double *host) {
+  const int n = which == 0 ? h->n_u : h->n_p;
+  if (!h->layout_on) {
+    HIP_CHECK(hipMemcpyAsync(host, dev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  } else {
+    h->io_stage.alloc((size_t)h->n_u + h->n_p);
+    perm_launch(h, which, h->io_stage.p, const_cast<double *>(dev), false);
+    HIP_CHECK(hipMemcpyAsync(host, h->io_stage.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  }
+  HIP_CHECK(hipStreamSynchronize(h->stream));
+}
+
+void vec_from_caller(nsx_handle *h, double *dev, const double *host, bool with_ghosts) {
+  const int dim = h->dim;
+  if (!h->dist) {
+    if (!h->layout_on) {
+      HIP_CHECK(hipMemcpyAsync(dev, host, ((size_t)h->n_u + h->n_p) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    } else {
+      h->io_stage.alloc((size_t)h->n_u + h->n_p);
+      HIP_CHECK(hipMemcpyAsync(h->io_stage.p, host, ((size_t)h->n_u + h->n_p) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+      perm_launch(h, 0, h->io_stage.p, dev, true);
+      perm_launch(h, 1, h->io_stage.p + h->n_u, dev + h->off_p, true);
+    }
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    return;
+  }
+  std::vector<double> loc(h->len_blk, 0.0);
+  for (int i = 0; i < h->N2; ++i)
+    for (int c = 0; c < dim; ++c) loc[(size_t)dim * node_to_internal(h, i) + c] = host[(size_t)dim * (h->goff_u + i) + c];
+  for (int i = 0; i < h->NP; ++i) loc[h->off_p + pnode_to_internal(h, i)] = host[(size_t)h->n_u_glob + h->goff_p + i];
+  if (with_ghosts) {
+    for (size_t g = 0; g < h->ghost_u.size(); ++g)
+      for (int c = 0; c < dim; ++c) loc[h->n_u + g * dim + c] = host[(size_t)dim * h->ghost_u[g] + c];
+    for (size_t g = 0; g < h->ghost_p.size(); ++g) loc[h->off_p + h->n_p + g] = host[(size_t)h->n_u_glob + h->ghost_p[g]];
+  }
+  HIP_CHECK(hipMemcpyAsync(dev, loc.data(), loc.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_CHECK(hipStreamSynchronize(h->stream));
+}
+
+void vec_to_caller(nsx_handle *h, const double *dev, double *host) {
+  const int dim = h->dim;
+  if (!h->dist) {
+    if (!h->layout_on) {
+      HIP_CHECK(hipMemcpyAsync(host, dev, ((size_t)h->n_u + h->n_p) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    } else {
+      h->io_stage.alloc((size_t)h->n_u + h->n_p);
+      perm_launch(h, 0, h->io_stage.p, const_cast<double *>(dev), false);
+      perm_launch(h, 1, h->io_stage.p + h->n_u, const_cast<double *>(dev) + h->off_p, false);
+      HIP_CHECK(hipMemcpyAsync(host, h->io_stage.p, ((size_t)h->n_u + h->n_p) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    return;
+  }
+  std::vector<double> loc(h->len_blk);
+  HIP_CHECK(hipMemcpyAsync(loc.data(), dev, loc.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_CHECK(hipStreamSynchronize(h->stream));
+  for (int i = 0; i < h->N2; ++i)
+    for (int c = 0; c < dim; ++c) host[(size_t)dim * (h->goff_u + i) + c] = loc[(size_t)dim * node_to_internal(h, i) + c];
+  for (int i = 0; i < h->NP; ++i) host[(size_t)h->n_u_glob + h->goff_p + i] = loc[h->off_p + pnode_to_internal(h, i)];
 }
 
 }  // namespace nsx
@@ -633,13 +723,88 @@ void setup_mesh(nsx_handle *h, int n_cells, int n_cells1, const double *cell_coo
   }
   build_schur_graph(h);
   build_row_splits(h);
-  default_ranks(h);
-  refresh_rank_products(h);
   HIP_CHECK(hipStreamSynchronize(h->stream));
   h->have_mesh = true;
   h->assembled = false;
+  h->prec_ready = false;
   h->schur_valid = false;
   h->bc_cache.clear();
+  for (int w = 0; w < 2; ++w) {
+    h->caller_graph[w] = nsx::Csr();
+    h->caller_pos[w].clear();
+  }
+}
+
+// The node numbering libnsx works in, the set-up products in that numbering, and the rank tables that go with it.
+// Without a layout request: the caller's numbering and the caller's tables.  With one (nsx_set_internal_layout): inside the
+// range of every rank of the caller the owned nodes are dealt to virtual ranks (bisection of the cells' centroids, lowest-id
+// ownership, first-touch order, colour order: host/layout.hpp) and renumbered rank by rank; ghosts keep their places.
+void install_mesh(nsx_handle *h) {
+  using namespace nsx;
+  const int dim = h->dim, nv = dim + 1, np2 = h->np2, np1 = h->np1;
+  const int n_cells = (int)(h->cell_n2_in.size() / np2);
+  h->cell_n2_h = h->cell_n2_in;
+  h->cell_n1_h = h->cell_n1_in;
+  h->layout_on = false;
+  h->layout_colours = h->layout_colours_p = 0;
+  LayoutOut lay;
+  if (h->layout_req_ranks > 0) {
+    std::vector<double> cen((size_t)n_cells * dim, 0.0);
+    for (int c = 0; c < n_cells; ++c)
+      for (int k = 0; k < nv; ++k)
+        for (int d = 0; d < dim; ++d) cen[(size_t)c * dim + d] += h->cell_coords_in[((size_t)c * nv + k) * dim + d] / nv;
+    LayoutIn in;
+    in.dim = dim;
+    in.n_cells = n_cells;
+    in.np2 = np2;
+    in.np1 = np1;
+    in.c2 = h->cell_n2_in.data();
+    in.c1 = h->cell_n1_in.data();
+    in.cen = cen.data();
+    in.N2 = h->N2;
+    in.NP = h->NP;
+    in.N2_all = h->N2_loc;
+    in.in_u_ptr = h->in_rank_u_h;
+    in.in_p_ptr = h->in_rank_p_h;
+    build_layout(in, h->layout_req_ranks, h->layout_req_order, h->layout_req_schur, lay);
+    h->perm2_h = lay.perm2;
+    h->perm1_h = lay.perm1;
+    h->iperm2_h.resize(h->N2);
+    h->iperm1_h.resize(h->NP);
+    for (int i = 0; i < h->N2; ++i) h->iperm2_h[h->perm2_h[i]] = i;
+    for (int i = 0; i < h->NP; ++i) h->iperm1_h[h->perm1_h[i]] = i;
+    for (auto &v : h->cell_n2_h)
+      if (v < h->N2) v = h->perm2_h[v];
+    for (auto &v : h->cell_n1_h)
+      if (v < h->NP) v = h->perm1_h[v];
+    h->perm2_d.upload(h->perm2_h, h->stream);
+    h->perm1_d.upload(h->perm1_h, h->stream);
+    h->layout_on = true;
+    h->layout_colours = lay.n_colours;
+    h->layout_colours_p = lay.n_colours_p;
+  }
+  setup_mesh(h, n_cells, h->n_cells1, h->cell_coords_in.data());
+  if (h->layout_on) {
+    h->rank_u_h = lay.u_ptr;
+    h->rank_p_h = lay.p_ptr;
+    h->sblk_h = lay.schur_ptr;
+    if (h->sblk_h.size() == h->rank_p_h.size()) h->sblk_h.clear();  // nothing was merged
+  } else {
+    h->rank_u_h = h->in_rank_u_h;
+    h->rank_p_h = h->in_rank_p_h;
+    h->sblk_h = h->in_sblk_h;
+  }
+  refresh_rank_products(h);
+  for (HaloPlan *p : {&h->haloU, &h->haloP}) {
+    if (p->send_idx_in.empty()) continue;
+    std::vector<int32_t> idx(p->send_idx_in);
+    if (h->layout_on)
+      for (auto &v : idx) v = (p == &h->haloU ? h->perm2_h : h->perm1_h)[v];
+    p->send_idx.upload(idx, h->stream);
+  }
+  if (getenv("NSX_DEBUG") && h->layout_on)
+    fprintf(stderr, "[nsx] internal layout: %d virtual ranks inside %d rank(s) of the caller, %d Schur blocks, %d / %d colours\n", (int)h->rank_u_h.size() - 1,
+            (int)h->in_rank_u_h.size() - 1, (int)(h->sblk_h.empty() ? h->rank_p_h.size() : h->sblk_h.size()) - 1, h->layout_colours, h->layout_colours_p);
 }
 
 void halo_plan(nsx_handle *h, nsx::HaloPlan &p, int n_own, int goff, const std::vector<int32_t> &ghosts, const int32_t *gpu_ptr,
@@ -653,7 +818,7 @@ void halo_plan(nsx_handle *h, nsx::HaloPlan &p, int n_own, int goff, const std::
     if (l < 0 || l >= n_own) NSX_THROW(NSX_ERR_ARG, "halo plan: node %d to send is not owned by this rank", send_nodes[k]);
     idx[k] = l;
   }
-  p.send_idx.upload(idx, h->stream);
+  p.send_idx_in = idx;  // uploaded by install_mesh, through the internal layout if there is one
   p.sendbuf.alloc((size_t)std::max<int32_t>(1, send_ptr[n_nbr]) * ncomp);
   // ghosts are sorted by global id, i.e. grouped by owner in rank order
   p.recv_ptr.assign((size_t)n_nbr + 1, 0);
@@ -696,7 +861,14 @@ int nsx_set_mesh(nsx_handle *h, int n_cells, int dpc, const int32_t *cell_dofs, 
   h->ghost_u.clear();
   h->ghost_p.clear();
   connectivity(h, n_cells, dpc, cell_dofs, n_u, n_p, [](int32_t g) { return g; }, [](int32_t g) { return g; });
-  setup_mesh(h, n_cells, n_cells, cell_coords);
+  h->cell_n2_in = h->cell_n2_h;
+  h->cell_n1_in = h->cell_n1_h;
+  h->cell_coords_in.assign(cell_coords, cell_coords + (size_t)n_cells * nv * dim);
+  h->n_cells1 = n_cells;
+  h->haloU.send_idx_in.clear();
+  h->haloP.send_idx_in.clear();
+  default_ranks(h);
+  install_mesh(h);
   NSX_CATCH(h)
 }
 
@@ -762,7 +934,12 @@ int nsx_set_mesh_distributed(nsx_handle *h, int n_cells, int n_cells1, int dpc, 
   }
   halo_plan(h, h->haloU, h->N2, h->goff_u, h->ghost_u, gpu_u_ptr, n_nbr, nbr, send_u_ptr, send_u_nodes, dim);
   halo_plan(h, h->haloP, h->NP, h->goff_p, h->ghost_p, gpu_p_ptr, n_nbr, nbr, send_p_ptr, send_p_nodes, 1);
-  setup_mesh(h, n_cells, n_cells1, cell_coords);
+  h->cell_n2_in = h->cell_n2_h;
+  h->cell_n1_in = h->cell_n1_h;
+  h->cell_coords_in.assign(cell_coords, cell_coords + (size_t)n_cells * nv * dim);
+  h->n_cells1 = n_cells1;
+  default_ranks(h);
+  install_mesh(h);
   NSX_CATCH(h)
 }
 
@@ -775,13 +952,19 @@ int nsx_set_ranks(nsx_handle *h, int n_ranks, const int32_t *u_ptr, const int32_
   for (int r = 0; r < n_ranks; ++r)
     if (u_ptr[r + 1] < u_ptr[r] || p_ptr[r + 1] < p_ptr[r]) NSX_THROW(NSX_ERR_ARG, "rank ranges must be ascending");
   HIP_CHECK(hipSetDevice(h->prm.device));
-  h->rank_u_h.resize((size_t)n_ranks + 1);
-  h->rank_p_h.resize((size_t)n_ranks + 1);
+  h->in_rank_u_h.resize((size_t)n_ranks + 1);
+  h->in_rank_p_h.resize((size_t)n_ranks + 1);
   for (int r = 0; r <= n_ranks; ++r) {
-    h->rank_u_h[r] = u_ptr[r] - h->goff_u;
-    h->rank_p_h[r] = p_ptr[r] - h->goff_p;
+    h->in_rank_u_h[r] = u_ptr[r] - h->goff_u;
+    h->in_rank_p_h[r] = p_ptr[r] - h->goff_p;
   }
-  refresh_rank_products(h);
+  if (h->layout_req_ranks > 0) {
+    install_mesh(h);  // the virtual ranks are a refinement of the caller's: lay the nodes out again inside the new ranges
+  } else {
+    h->rank_u_h = h->in_rank_u_h;
+    h->rank_p_h = h->in_rank_p_h;
+    refresh_rank_products(h);
+  }
   NSX_CATCH(h)
 }
 
@@ -791,43 +974,26 @@ int nsx_set_schur_blocks(nsx_handle *h, int n_blocks, const int32_t *p_ptr) {
   if (n_blocks < 1 || !p_ptr || p_ptr[0] != h->goff_p || p_ptr[n_blocks] != h->goff_p + h->NP) NSX_THROW(NSX_ERR_ARG, "bad Schur block table");
   for (int r = 0; r < n_blocks; ++r)
     if (p_ptr[r + 1] < p_ptr[r]) NSX_THROW(NSX_ERR_ARG, "Schur block ranges must be ascending");
+  if (h->layout_req_ranks > 0)
+    NSX_THROW(NSX_ERR_ARG, "with an internal layout the Schur ILU blocks are unions of virtual ranks: pass schur_max_rows to nsx_set_internal_layout");
   HIP_CHECK(hipSetDevice(h->prm.device));
-  h->sblk_h.resize((size_t)n_blocks + 1);
-  for (int r = 0; r <= n_blocks; ++r) h->sblk_h[r] = p_ptr[r] - h->goff_p;
+  h->in_sblk_h.resize((size_t)n_blocks + 1);
+  for (int r = 0; r <= n_blocks; ++r) h->in_sblk_h[r] = p_ptr[r] - h->goff_p;
+  h->sblk_h = h->in_sblk_h;
   refresh_rank_products(h);
   NSX_CATCH(h)
 }
 
-// ---- state: host vectors use the GLOBAL numbering [n_u_glob | n_p_glob]; a rank reads owned + ghost entries and writes owned ones
+// ---- state: host vectors use the caller's GLOBAL numbering [n_u_glob | n_p_glob]; a rank reads owned + ghost entries and writes owned ones
 static int vec_io(nsx_handle *h, nsx::DevBuf<double> &v, double *out, const double *in) {
   NSX_TRY(h)
   if (!h->have_mesh) NSX_THROW(NSX_ERR_ARG, "nsx_set_mesh first");
   HIP_CHECK(hipSetDevice(h->prm.device));
-  const int dim = h->dim;
-  if (!h->dist) {
-    const size_t n = (size_t)h->n_u + h->n_p;
-    if (in) {
-      HIP_CHECK(hipMemcpyAsync(v.p, in, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-      HIP_CHECK(hipStreamSynchronize(h->stream));
-    } else {
-      if (!out) NSX_THROW(NSX_ERR_ARG, "null output");
-      v.download(out, n, h->stream);
-    }
-  } else if (in) {
-    std::vector<double> loc(h->len_blk);
-    for (int i = 0; i < h->n_u; ++i) loc[i] = in[(size_t)dim * h->goff_u + i];
-    for (size_t g = 0; g < h->ghost_u.size(); ++g)
-      for (int c = 0; c < dim; ++c) loc[h->n_u + g * dim + c] = in[(size_t)dim * h->ghost_u[g] + c];
-    for (int i = 0; i < h->n_p; ++i) loc[h->off_p + i] = in[(size_t)h->n_u_glob + h->goff_p + i];
-    for (size_t g = 0; g < h->ghost_p.size(); ++g) loc[h->off_p + h->n_p + g] = in[(size_t)h->n_u_glob + h->ghost_p[g]];
-    HIP_CHECK(hipMemcpyAsync(v.p, loc.data(), loc.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIP_CHECK(hipStreamSynchronize(h->stream));
+  if (in) {
+    nsx::vec_from_caller(h, v.p, in, true);
   } else {
     if (!out) NSX_THROW(NSX_ERR_ARG, "null output");
-    std::vector<double> loc(h->len_blk);
-    v.download(loc.data(), loc.size(), h->stream);
-    for (int i = 0; i < h->n_u; ++i) out[(size_t)dim * h->goff_u + i] = loc[i];
-    for (int i = 0; i < h->n_p; ++i) out[(size_t)h->n_u_glob + h->goff_p + i] = loc[h->off_p + i];
+    nsx::vec_to_caller(h, v.p, out);
   }
   NSX_CATCH(h)
 }
@@ -843,7 +1009,50 @@ int nsx_get_solution_ghosted(nsx_handle *h, double *s) { return h ? vec_io(h, h-
 int nsx_get_rhs(nsx_handle *h, double *s) { return h ? vec_io(h, h->rhs, s, nullptr) : NSX_ERR_ARG; }
 int nsx_set_rhs(nsx_handle *h, const double *s) { return (h && s) ? vec_io(h, h->rhs, nullptr, s) : NSX_ERR_ARG; }
 
-// ---- exports
+// ---- exports: graphs and values in the CALLER's numbering
+// scalar velocity graph (0) / Schur graph (1) as the caller numbers their rows and columns, columns sorted, and for every entry its
+// position in the internal CSR (identity without an internal layout)
+static const nsx::Csr &caller_graph(nsx_handle *h, int which) {
+  const nsx::Csr &g = which == 0 ? h->gA.host : h->gS.host;
+  if (!h->layout_on) return g;
+  if (h->caller_graph[which].n_rows == g.n_rows && (int64_t)h->caller_pos[which].size() == g.nnz()) return h->caller_graph[which];
+  const std::vector<int32_t> &perm = which == 0 ? h->perm2_h : h->perm1_h, &iperm = which == 0 ? h->iperm2_h : h->iperm1_h;
+  const int n = g.n_rows;
+  nsx::Csr c;
+  c.n_rows = n;
+  c.n_cols = g.n_cols;
+  c.rowptr.assign((size_t)n + 1, 0);
+  c.colind.resize(g.nnz());
+  std::vector<int32_t> &pos = h->caller_pos[which];
+  pos.resize(g.nnz());
+  std::vector<std::pair<int32_t, int32_t>> row;
+  for (int i = 0; i < n; ++i) {
+    const int ii = perm[i];
+    row.clear();
+    for (int k = g.rowptr[ii]; k < g.rowptr[ii + 1]; ++k) row.emplace_back(g.colind[k] < n ? iperm[g.colind[k]] : g.colind[k], k);
+    std::sort(row.begin(), row.end());
+    c.rowptr[i + 1] = c.rowptr[i] + (int32_t)row.size();
+    for (size_t q = 0; q < row.size(); ++q) {
+      c.colind[c.rowptr[i] + q] = row[q].first;
+      pos[c.rowptr[i] + q] = row[q].second;
+    }
+  }
+  h->caller_graph[which] = std::move(c);
+  return h->caller_graph[which];
+}
+static void values_to_caller(nsx_handle *h, int which, const nsx::DevBuf<double> &src, double *values) {
+  const int64_t nnz = which == 0 ? h->gA.nnz() : h->gS.nnz();
+  if (!h->layout_on) {
+    src.download(values, nnz, h->stream);
+    return;
+  }
+  caller_graph(h, which);
+  std::vector<double> v(nnz);
+  src.download(v.data(), nnz, h->stream);
+  const std::vector<int32_t> &pos = h->caller_pos[which];
+  for (int64_t k = 0; k < nnz; ++k) values[k] = v[pos[k]];
+}
+
 int nsx_scalar_graph_nnz(nsx_handle *h, int which, int64_t *nnz) {
   if (!h || !nnz || !h->have_mesh || which < 0 || which > 1) return NSX_ERR_ARG;
   *nnz = which == 0 ? h->gA.nnz() : h->gS.nnz();
@@ -851,7 +1060,7 @@ int nsx_scalar_graph_nnz(nsx_handle *h, int which, int64_t *nnz) {
 }
 int nsx_scalar_graph(nsx_handle *h, int which, int32_t *rowptr, int32_t *colind) {
   if (!h || !rowptr || !colind || !h->have_mesh || which < 0 || which > 1) return NSX_ERR_ARG;
-  const nsx::Csr &g = which == 0 ? h->gA.host : h->gS.host;
+  const nsx::Csr &g = caller_graph(h, which);
   std::copy(g.rowptr.begin(), g.rowptr.end(), rowptr);
   std::copy(g.colind.begin(), g.colind.end(), colind);
   return NSX_OK;
@@ -860,7 +1069,7 @@ int nsx_ilu_get(nsx_handle *h, int which, double *values) {
   NSX_TRY(h)
   if (!values || which < 0 || which > 1 || !h->prec_ready) NSX_THROW(NSX_ERR_ARG, "no factors: call nsx_prec_initialize first");
   HIP_CHECK(hipSetDevice(h->prm.device));
-  (which == 0 ? h->luF : h->luS).download(values, which == 0 ? h->gA.nnz() : h->gS.nnz(), h->stream);
+  values_to_caller(h, which, which == 0 ? h->luF : h->luS, values);
   NSX_CATCH(h)
 }
 int nsx_schur_nnz(nsx_handle *h, int64_t *nnz) { return nsx_scalar_graph_nnz(h, 1, nnz); }
@@ -870,7 +1079,7 @@ int nsx_schur_get(nsx_handle *h, int32_t *rowptr, int32_t *colind, double *value
   HIP_CHECK(hipSetDevice(h->prm.device));
   int rc = nsx_scalar_graph(h, 1, rowptr, colind);
   if (rc) NSX_THROW(rc, "bad arguments");
-  h->vSchur.download(values, h->gS.nnz(), h->stream);
+  values_to_caller(h, 1, h->vSchur, values);
   NSX_CATCH(h)
 }
 
@@ -883,13 +1092,17 @@ int nsx_export_block(nsx_handle *h, int which, int block, int n_rows, const int3
   const int dim = h->dim;
   const int64_t nnz = rowptr[n_rows];
   std::fill(values, values + nnz, 0.0);
+  // the caller's graph is in the caller's numbering: node ids go through the internal layout, components stay
+  auto n2 = [&](int32_t node) { return nsx::node_to_internal(h, node); };
+  auto n1 = [&](int32_t node) { return nsx::pnode_to_internal(h, node); };
   if (which == 4) {
     if (block != 3 || n_rows != h->n_p) NSX_THROW(NSX_ERR_ARG, "pressure_mass lives in block (1,1)");
     std::vector<double> v(h->gPM.nnz());
     h->vPM.download(v.data(), v.size(), h->stream);
     for (int i = 0; i < n_rows; ++i)
       for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
-        const int e = nsx::find_in_row(h->gPM.host, i, colind[k]);
+        if (colind[k] < 0 || colind[k] >= h->n_p) NSX_THROW(NSX_ERR_ARG, "column %d out of range in row %d", colind[k], i);
+        const int e = nsx::find_in_row(h->gPM.host, n1(i), n1(colind[k]));
         if (e >= 0) values[k] = v[e];
       }
   } else if (block == 0) {
@@ -899,10 +1112,11 @@ int nsx_export_block(nsx_handle *h, int which, int block, int n_rows, const int3
     std::vector<double> v(h->gA.nnz());
     src->download(v.data(), v.size(), h->stream);
     for (int i = 0; i < n_rows; ++i) {
-      const int node = i / dim, c = i % dim;
+      const int node = n2(i / dim), c = i % dim;
       for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+        if (colind[k] < 0 || colind[k] >= h->n_u) NSX_THROW(NSX_ERR_ARG, "column %d out of range in row %d", colind[k], i);
         if (colind[k] % dim != c) continue;  // cross-component slots are structural zeros in the reference
-        const int e = nsx::find_in_row(h->gA.host, node, colind[k] / dim);
+        const int e = nsx::find_in_row(h->gA.host, node, n2(colind[k] / dim));
         if (e >= 0) values[k] = v[e];
       }
     }
@@ -915,11 +1129,12 @@ int nsx_export_block(nsx_handle *h, int which, int block, int n_rows, const int3
     (isG ? h->vG : h->vB).download(v.data(), v.size(), h->stream);
     for (int i = 0; i < n_rows; ++i)
       for (int k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+        if (colind[k] < 0 || colind[k] >= (isG ? h->n_p : h->n_u)) NSX_THROW(NSX_ERR_ARG, "column %d out of range in row %d", colind[k], i);
         if (isG) {
-          const int e = nsx::find_in_row(g.host, i / dim, colind[k]);
+          const int e = nsx::find_in_row(g.host, n2(i / dim), n1(colind[k]));
           if (e >= 0) values[k] = v[(size_t)e * dim + i % dim];
         } else {
-          const int e = nsx::find_in_row(g.host, i, colind[k] / dim);
+          const int e = nsx::find_in_row(g.host, n1(i), n2(colind[k] / dim));
           if (e >= 0) values[k] = v[(size_t)e * dim + colind[k] % dim];
         }
       }
@@ -927,6 +1142,48 @@ int nsx_export_block(nsx_handle *h, int which, int block, int n_rows, const int3
     NSX_THROW(NSX_ERR_ARG, "bad block id");
   }
   NSX_CATCH(h)
+}
+
+// ---- internal layout
+int nsx_set_internal_layout(nsx_handle *h, int n_virtual_ranks, int order, int schur_max_rows) {
+  NSX_TRY(h)
+  if (n_virtual_ranks < 0 || order < NSX_ORDER_FIRST_TOUCH || order > NSX_ORDER_COLOUR_ALL || schur_max_rows < 0)
+    NSX_THROW(NSX_ERR_ARG, "bad layout request (ranks %d, order %d, Schur rows %d)", n_virtual_ranks, order, schur_max_rows);
+  if (h->layout_req_ranks == n_virtual_ranks && h->layout_req_order == order && h->layout_req_schur == schur_max_rows) return NSX_OK;
+  h->layout_req_ranks = n_virtual_ranks;
+  h->layout_req_order = order;
+  h->layout_req_schur = schur_max_rows;
+  if (h->have_mesh) {  // otherwise nsx_set_mesh(_distributed) applies the request
+    HIP_CHECK(hipSetDevice(h->prm.device));
+    if (n_virtual_ranks > 0) h->in_sblk_h.clear();
+    install_mesh(h);
+  }
+  NSX_CATCH(h)
+}
+int nsx_layout_info(nsx_handle *h, int info[5]) {
+  if (!h || !info || !h->have_mesh) return NSX_ERR_ARG;
+  info[0] = h->layout_on ? 1 : 0;
+  info[1] = (int)h->rank_u_h.size() - 1;
+  info[2] = (int)(h->sblk_h.empty() ? h->rank_p_h.size() : h->sblk_h.size()) - 1;
+  info[3] = h->layout_colours;
+  info[4] = h->layout_colours_p;
+  return NSX_OK;
+}
+int nsx_layout_get(nsx_handle *h, int32_t *node_perm, int32_t *pnode_perm, int32_t *u_ptr, int32_t *p_ptr, int32_t *schur_ptr) {
+  if (!h || !h->have_mesh) return NSX_ERR_ARG;
+  if (node_perm)
+    for (int i = 0; i < h->N2; ++i) node_perm[i] = h->goff_u + nsx::node_to_internal(h, i);
+  if (pnode_perm)
+    for (int i = 0; i < h->NP; ++i) pnode_perm[i] = h->goff_p + nsx::pnode_to_internal(h, i);
+  if (u_ptr)
+    for (size_t r = 0; r < h->rank_u_h.size(); ++r) u_ptr[r] = h->goff_u + h->rank_u_h[r];
+  if (p_ptr)
+    for (size_t r = 0; r < h->rank_p_h.size(); ++r) p_ptr[r] = h->goff_p + h->rank_p_h[r];
+  if (schur_ptr) {
+    const std::vector<int32_t> &sb = h->sblk_h.empty() ? h->rank_p_h : h->sblk_h;
+    for (size_t r = 0; r < sb.size(); ++r) schur_ptr[r] = h->goff_p + sb[r];
+  }
+  return NSX_OK;
 }
 
 // ---- profiling

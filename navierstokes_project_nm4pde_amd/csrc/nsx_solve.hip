@@ -567,15 +567,14 @@ int nsx_prec_vmult(nsx_handle *h, int prec_type, double inner_rtol, int inner_ma
     HIP_CHECK(hipSetDevice(h->prm.device));
     const int n = h->n_u + h->n_p;
     nsx::Tmp d(h, n), s(h, n);
-    HIP_CHECK(hipMemcpyAsync(s.p(), src, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIP_CHECK(hipMemcpyAsync(d.p(), dst, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));  // aSIMPLE reads dst as initial guess
+    nsx::vec_from_caller(h, s.p(), src, false);
+    nsx::vec_from_caller(h, d.p(), dst, false);  // aSIMPLE reads dst as initial guess
     if (stats) memset(stats, 0, sizeof(*stats));
     h->defer_red = false;
     h->pending_red.clear();
     nsx::prec_vmult(h, prec_type, inner_rtol, inner_maxiter, d.p(), s.p(), stats);
     if (stats) stats->persistent_fallbacks = h->n_persistent_fallbacks;
-    HIP_CHECK(hipMemcpyAsync(dst, d.p(), (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_CHECK(hipStreamSynchronize(h->stream));
+    nsx::vec_to_caller(h, d.p(), dst);
   })
 }
 
@@ -585,15 +584,9 @@ int nsx_system_vmult(nsx_handle *h, double *dst, const double *src) {
     HIP_CHECK(hipSetDevice(h->prm.device));
     nsx::Tmp d(h, h->len_blk), s(h, h->len_blk);
     // host vectors are globally indexed: pick the owned entries (ghosts come through the halo exchange of the product)
-    std::vector<double> loc(h->len_blk, 0.0);
-    for (int i = 0; i < h->n_u; ++i) loc[i] = src[(size_t)h->dim * h->goff_u + i];
-    for (int i = 0; i < h->n_p; ++i) loc[h->off_p + i] = src[(size_t)h->n_u_glob + h->goff_p + i];
-    HIP_CHECK(hipMemcpyAsync(s.p(), loc.data(), loc.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    nsx::vec_from_caller(h, s.p(), src, false);
     nsx::spmv_saddle(h, s.p(), d.p());
-    HIP_CHECK(hipMemcpyAsync(loc.data(), d.p(), loc.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_CHECK(hipStreamSynchronize(h->stream));
-    for (int i = 0; i < h->n_u; ++i) dst[(size_t)h->dim * h->goff_u + i] = loc[i];
-    for (int i = 0; i < h->n_p; ++i) dst[(size_t)h->n_u_glob + h->goff_p + i] = loc[h->off_p + i];
+    nsx::vec_to_caller(h, d.p(), dst);
   })
 }
 
@@ -605,11 +598,10 @@ int nsx_ilu_apply(nsx_handle *h, int which, double *dst, const double *src) {
     HIP_CHECK(hipSetDevice(h->prm.device));
     const int n = which == 0 ? h->n_u : h->n_p;
     nsx::Tmp d(h, n), s(h, n);
-    HIP_CHECK(hipMemcpyAsync(s.p(), src, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    nsx::part_from_caller(h, which, s.p(), src);
     if (which == 0) nsx::ilu_solve(h, h->gA, h->schedF, h->luF.p, s.p(), d.p(), h->dim, "ilu_solve_F");
     else nsx::ilu_solve(h, h->gS, h->schedS, h->luS.p, s.p(), d.p(), 1, "ilu_solve_S");
-    HIP_CHECK(hipMemcpyAsync(dst, d.p(), (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_CHECK(hipStreamSynchronize(h->stream));
+    nsx::part_to_caller(h, which, d.p(), dst);
   })
 }
 

@@ -73,6 +73,8 @@ def _lib():
         "nsxh_tables_dN1": (_f64p, [vp]),
         "nsxh_ilu_stream_stats": (C.c_int, [C.c_int, _i32p, _i32p, C.c_int, _i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
         "nsxh_ilu_stream_apply": (C.c_int, [C.c_int, _i32p, _i32p, C.c_int, _i32p, C.c_int, C.c_int, C.c_int, C.c_int, _f64p, _f64p, _f64p]),
+        "nsxh_internal_layout": (C.c_int, [C.c_int, C.c_int, C.c_int, _i32p, _f64p, C.c_int, C.c_int, C.c_int, _i32p, _i32p, C.c_int, C.c_int, C.c_int,
+                                           _i32p, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -322,3 +324,77 @@ def merge_ranks(ptr, max_rows):
     if out[-1] != ptr[-1]:
         out.append(int(ptr[-1]))
     return np.array(out, dtype=np.int32)
+
+
+def internal_layout(dofs, n_virtual, order="colour", schur_max_rows=0):
+    """The layout libnsx gives itself behind nsx_set_internal_layout (host/layout.hpp) for the serial DoF table `dofs` whose
+    subdomains are the caller's ranks: dict with node_perm / pnode_perm (caller node -> internal node), u_ptr / p_ptr (internal
+    node ranges of the virtual ranks), schur_ptr (Schur ILU blocks), colours."""
+    L = _lib()
+    cd = np.ascontiguousarray(dofs.cell_dofs, dtype=np.int32)
+    cc = np.ascontiguousarray(dofs.cell_coords, dtype=np.float64)
+    iu, ip = (np.ascontiguousarray(a, dtype=np.int32) for a in (dofs.owned_u_ptr, dofs.owned_p_ptr))
+    cap = int(n_virtual) + len(iu) + 1
+    perm2, perm1 = np.empty(dofs.n_nodes_p2, np.int32), np.empty(dofs.n_nodes_p1, np.int32)
+    u_ptr, p_ptr, s_ptr = (np.empty(cap, np.int32) for _ in range(3))
+    nr, ns, col = C.c_int32(), C.c_int32(), (C.c_int32 * 2)()
+    rc = L.nsxh_internal_layout(dofs.dim, dofs.n_cells, dofs.dofs_per_cell, cd.ctypes.data_as(_i32p), cc.ctypes.data_as(_f64p), dofs.n_u, dofs.n_p,
+                                len(iu) - 1, iu.ctypes.data_as(_i32p), ip.ctypes.data_as(_i32p), int(n_virtual), DoFs.ORDERINGS[order], int(schur_max_rows),
+                                perm2.ctypes.data_as(_i32p), perm1.ctypes.data_as(_i32p), C.byref(nr), u_ptr.ctypes.data_as(_i32p),
+                                p_ptr.ctypes.data_as(_i32p), C.byref(ns), s_ptr.ctypes.data_as(_i32p), col)
+    if rc:
+        raise ValueError("nsxh_internal_layout failed (%d)" % rc)
+    return {"node_perm": perm2, "pnode_perm": perm1, "u_ptr": u_ptr[:nr.value + 1].copy(), "p_ptr": p_ptr[:nr.value + 1].copy(),
+            "schur_ptr": s_ptr[:ns.value + 1].copy(), "colours": (int(col[0]), int(col[1]))}
+
+
+class PermutedDoFs:
+    """The DoF table `dofs` with its P2 / P1 nodes renumbered (node_perm / pnode_perm: old node -> new node) and a new rank table:
+    the same mesh, cells in the same order, every index array mapped.  What a caller would hand over had it numbered its DoFs the way
+    libnsx's internal layout does; the oracle runs on it when the device was given `dofs` + nsx_set_internal_layout."""
+
+    def __init__(self, dofs, node_perm, pnode_perm, u_ptr, p_ptr):
+        self.base, self.mesh = dofs, dofs.mesh
+        self.dim, self.n_cells, self.dofs_per_cell = dofs.dim, dofs.n_cells, dofs.dofs_per_cell
+        self.n_nodes_p2, self.n_nodes_p1, self.n_u, self.n_p, self.n_dofs = dofs.n_nodes_p2, dofs.n_nodes_p1, dofs.n_u, dofs.n_p, dofs.n_dofs
+        self.node_perm, self.pnode_perm = np.asarray(node_perm, dtype=np.int64), np.asarray(pnode_perm, dtype=np.int64)
+        dim = self.dim
+        dmap = np.empty(self.n_dofs, dtype=np.int64)      # old dof -> new dof
+        for c in range(dim):
+            dmap[c:self.n_u:dim] = dim * self.node_perm + c
+        dmap[self.n_u:] = self.n_u + self.pnode_perm
+        self.dof_map = dmap
+        self.cell_dofs = dmap[np.asarray(dofs.cell_dofs)].astype(np.int32)
+        self.cell_coords = dofs.cell_coords
+        sp = np.empty_like(np.asarray(dofs.support_points))
+        sp[dmap] = dofs.support_points
+        self.support_points = sp
+        self.owned_u_ptr, self.owned_p_ptr = np.asarray(u_ptr, dtype=np.int32), np.asarray(p_ptr, dtype=np.int32)
+        self.n_subdomains = len(self.owned_u_ptr) - 1
+        self._ref = {}
+
+    def to_new(self, x):
+        """vector in the old numbering -> the same finite-element function in the new one"""
+        out = np.empty_like(np.asarray(x, dtype=np.float64))
+        out[self.dof_map] = x
+        return out
+
+    def to_old(self, y):
+        return np.asarray(y)[self.dof_map]
+
+    def boundary_dofs(self, boundary_id):
+        return np.sort(self.dof_map[self.base.boundary_dofs(boundary_id)]).astype(np.int32)
+
+    def reference_sparsity(self, block):
+        if block not in self._ref:
+            rp, ci = self.base.reference_sparsity(block)
+            nu = self.n_u
+            rmap = self.dof_map[:nu] if block in (0, 1) else self.dof_map[nu:] - nu
+            cmap = self.dof_map[:nu] if block in (0, 2) else self.dof_map[nu:] - nu
+            n = len(rp) - 1
+            rows = np.repeat(np.arange(n), np.diff(rp))
+            nr, ncol = rmap[rows], cmap[ci]
+            order = np.lexsort((ncol, nr))
+            cnt = np.bincount(nr, minlength=n)
+            self._ref[block] = (np.concatenate(([0], np.cumsum(cnt))).astype(np.int32), ncol[order].astype(np.int32))
+        return self._ref[block]

@@ -27,6 +27,7 @@
 
 #include "graph.hpp"
 #include "ilu_stream.hpp"
+#include "layout.hpp"
 
 namespace {
 
@@ -315,30 +316,7 @@ void finish_mesh(nsxh_mesh &m) {
   m.n_subdomains = 1;
 }
 
-void rcb(const std::vector<double> &cen, int dim, std::vector<int32_t> &idx, size_t lo, size_t hi, int nparts, int first,
-         std::vector<int32_t> &out) {
-  if (nparts <= 1 || hi - lo <= 1) {
-    for (size_t k = lo; k < hi; ++k) out[idx[k]] = first;
-    return;
-  }
-  double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
-  for (size_t k = lo; k < hi; ++k)
-    for (int d = 0; d < dim; ++d) {
-      mn[d] = std::min(mn[d], cen[(size_t)idx[k] * dim + d]);
-      mx[d] = std::max(mx[d], cen[(size_t)idx[k] * dim + d]);
-    }
-  int ax = 0;
-  for (int d = 1; d < dim; ++d)
-    if (mx[d] - mn[d] > mx[ax] - mn[ax]) ax = d;
-  const int nl = nparts / 2;
-  const size_t mid = lo + (size_t)((double)(hi - lo) * nl / nparts + 0.5);
-  std::nth_element(idx.begin() + lo, idx.begin() + mid, idx.begin() + hi, [&](int32_t a, int32_t b) {
-    const double xa = cen[(size_t)a * dim + ax], xb = cen[(size_t)b * dim + ax];
-    return xa != xb ? xa < xb : a < b;
-  });
-  rcb(cen, dim, idx, lo, mid, nl, first, out);
-  rcb(cen, dim, idx, mid, hi, nparts - nl, first + nl, out);
-}
+using nsx::rcb;  // host/layout.hpp: the bisection libnsx runs behind nsx_set_internal_layout as well
 
 // Recursive coordinate bisection that balances what a subdomain will OWN, not how many cells it has.  deal.II gives an
 // interface node to the lowest subdomain id touching it, so with equal cell counts the low ids own far more nodes than the
@@ -728,39 +706,9 @@ struct nsxh_dofs {
 // (13 on the 3D channel meshes against up to 93 levels with first-touch numbering), which is what bounds the
 // triangular solves on the GPU.  Ownership, the rank ranges and the pressure numbering are untouched.
 static void renumber_by_colour(nsxh_dofs *d, int np2) {
-  const int nc = d->n_cells, n2 = (int)d->node_owner.size();
-  std::vector<int32_t> nptr(n2 + 1, 0), ncell;
-  for (size_t k = 0; k < d->cell_nodes2.size(); ++k) nptr[d->cell_nodes2[k] + 1]++;
-  for (int i = 0; i < n2; ++i) nptr[i + 1] += nptr[i];
-  ncell.resize(nptr[n2]);
-  {
-    std::vector<int32_t> fill(nptr.begin(), nptr.end() - 1);
-    for (int c = 0; c < nc; ++c)
-      for (int a = 0; a < np2; ++a) ncell[fill[d->cell_nodes2[(size_t)c * np2 + a]]++] = c;
-  }
-  std::vector<int32_t> colour(n2, -1), perm(n2);
-  std::vector<uint8_t> used;
-  int max_col = 0;
-  for (int i = 0; i < n2; ++i) {
-    used.assign(max_col + 2, 0);
-    for (int k = nptr[i]; k < nptr[i + 1]; ++k)
-      for (int a = 0; a < np2; ++a) {
-        const int j = d->cell_nodes2[(size_t)ncell[k] * np2 + a];
-        if (j != i && d->node_owner[j] == d->node_owner[i] && colour[j] >= 0) used[colour[j]] = 1;
-      }
-    int c = 0;
-    while (used[c]) ++c;
-    colour[i] = c;
-    max_col = std::max(max_col, c + 1);
-  }
-  for (int s = 0; s < d->n_sub; ++s) {
-    const int r0 = d->owned_u_ptr[s], r1 = d->owned_u_ptr[s + 1];
-    std::vector<int32_t> idx(r1 - r0);
-    std::iota(idx.begin(), idx.end(), r0);
-    std::stable_sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) { return colour[a] < colour[b]; });
-    for (int k = 0; k < r1 - r0; ++k) perm[idx[k]] = r0 + k;
-  }
-  d->n_colours = max_col;
+  const int n2 = (int)d->node_owner.size();
+  std::vector<int32_t> perm;
+  d->n_colours = nsx::colour_perm(n2, d->n_cells, np2, d->cell_nodes2.data(), d->node_owner.data(), d->owned_u_ptr, perm);
   for (auto &v : d->vertex_node)
     if (v >= 0) v = perm[v];
   for (auto &kv : d->edge_node) kv.second = perm[kv.second];
@@ -772,51 +720,10 @@ static void renumber_by_colour(nsxh_dofs *d, int np2) {
 // whose per-rank ILU(0) is applied in every CG iteration.  With few large ranks (mpirun -n 1, one rank per GPU) the first-touch
 // pressure numbering gives that factorisation thousands of dependency levels; by colour it has as many as there are colours.
 static int renumber_pressure_by_colour(nsxh_dofs *d, int np2, int nv) {
-  const int nc = d->n_cells, n1 = (int)d->pnode_owner.size(), n2 = (int)d->node_owner.size();
-  auto incidence = [&](const std::vector<int32_t> &conn, int per_cell, int n, std::vector<int32_t> &ptr, std::vector<int32_t> &cells) {
-    ptr.assign((size_t)n + 1, 0);
-    for (size_t k = 0; k < conn.size(); ++k) ptr[conn[k] + 1]++;
-    for (int i = 0; i < n; ++i) ptr[i + 1] += ptr[i];
-    cells.resize(ptr[n]);
-    std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
-    for (int c = 0; c < nc; ++c)
-      for (int a = 0; a < per_cell; ++a) cells[fill[conn[(size_t)c * per_cell + a]]++] = c;
-  };
-  std::vector<int32_t> pptr, pcell, nptr, ncell;
-  incidence(d->cell_nodes1, nv, n1, pptr, pcell);
-  incidence(d->cell_nodes2, np2, n2, nptr, ncell);
-  std::vector<int32_t> colour(n1, -1), perm(n1), seen2(n2, -1), seenc(nc, -1);
-  std::vector<uint8_t> used;
-  int max_col = 0;
-  for (int i = 0; i < n1; ++i) {
-    used.assign(max_col + 2, 0);
-    for (int k = pptr[i]; k < pptr[i + 1]; ++k)
-      for (int a = 0; a < np2; ++a) {
-        const int m2 = d->cell_nodes2[(size_t)pcell[k] * np2 + a];
-        if (seen2[m2] == i) continue;
-        seen2[m2] = i;
-        for (int q = nptr[m2]; q < nptr[m2 + 1]; ++q) {
-          const int c2 = ncell[q];
-          if (seenc[c2] == i) continue;
-          seenc[c2] = i;
-          for (int b = 0; b < nv; ++b) {
-            const int j = d->cell_nodes1[(size_t)c2 * nv + b];
-            if (j != i && d->pnode_owner[j] == d->pnode_owner[i] && colour[j] >= 0) used[colour[j]] = 1;
-          }
-        }
-      }
-    int c = 0;
-    while (used[c]) ++c;
-    colour[i] = c;
-    if (c + 1 > max_col) max_col = c + 1;
-  }
-  for (int s = 0; s < d->n_sub; ++s) {
-    const int r0 = d->owned_p_ptr[s], r1 = d->owned_p_ptr[s + 1];
-    std::vector<int32_t> idx(r1 - r0);
-    std::iota(idx.begin(), idx.end(), r0);
-    std::stable_sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) { return colour[a] < colour[b]; });
-    for (int k = 0; k < r1 - r0; ++k) perm[idx[k]] = r0 + k;
-  }
+  const int n1 = (int)d->pnode_owner.size(), n2 = (int)d->node_owner.size();
+  std::vector<int32_t> perm;
+  const int max_col = nsx::colour_perm_schur(n1, n2, d->n_cells, np2, nv, d->cell_nodes2.data(), d->cell_nodes1.data(), d->pnode_owner.data(),
+                                             d->owned_p_ptr, perm);
   for (auto &v : d->vertex_pnode)
     if (v >= 0) v = perm[v];
   for (auto &v : d->cell_nodes1) v = perm[v];
@@ -1466,4 +1373,51 @@ extern "C" int nsxh_ilu_stream_apply(int n_rows, const int32_t *rowptr, const in
   } catch (const std::exception &) {
     return -1;
   }
+}
+
+// ---------------------------------------------------------------- test hook: the internal layout of the device library
+// (host/layout.hpp is what nsx_set_internal_layout runs; this entry point lets the CPU tests build a layout for any serial DoF table)
+extern "C" int nsxh_internal_layout(int dim, int n_cells, int dofs_per_cell, const int32_t *cell_dofs, const double *cell_coords, int n_u, int n_p,
+                                    int n_in_ranks, const int32_t *in_u_ptr, const int32_t *in_p_ptr, int n_virtual, int order, int schur_max_rows,
+                                    int32_t *node_perm, int32_t *pnode_perm, int32_t *n_ranks, int32_t *u_ptr, int32_t *p_ptr, int32_t *n_schur,
+                                    int32_t *schur_ptr, int32_t *colours) {
+  if ((dim != 2 && dim != 3) || n_cells < 1 || !cell_dofs || !cell_coords || n_in_ranks < 1 || !in_u_ptr || !in_p_ptr || n_virtual < 1 || n_u % dim) return -1;
+  const int nv = dim + 1, nl = dim == 2 ? 3 : 6, np2 = nv + nl;
+  if (dofs_per_cell != nv * (dim + 1) + nl * dim) return -1;
+  std::vector<int32_t> c2((size_t)n_cells * np2), c1((size_t)n_cells * nv);
+  std::vector<double> cen((size_t)n_cells * dim, 0.0);
+  for (int c = 0; c < n_cells; ++c) {
+    const int32_t *cd = cell_dofs + (size_t)c * dofs_per_cell;
+    for (int a = 0; a < np2; ++a) c2[(size_t)c * np2 + a] = cd[a < nv ? (dim + 1) * a : nv * (dim + 1) + dim * (a - nv)] / dim;
+    for (int v = 0; v < nv; ++v) c1[(size_t)c * nv + v] = cd[(dim + 1) * v + dim] - n_u;
+    for (int k = 0; k < nv; ++k)
+      for (int d = 0; d < dim; ++d) cen[(size_t)c * dim + d] += cell_coords[((size_t)c * nv + k) * dim + d] / nv;
+  }
+  nsx::LayoutIn in;
+  in.dim = dim;
+  in.n_cells = n_cells;
+  in.np2 = np2;
+  in.np1 = nv;
+  in.c2 = c2.data();
+  in.c1 = c1.data();
+  in.cen = cen.data();
+  in.N2 = in.N2_all = n_u / dim;
+  in.NP = n_p;
+  in.in_u_ptr.assign(in_u_ptr, in_u_ptr + n_in_ranks + 1);
+  in.in_p_ptr.assign(in_p_ptr, in_p_ptr + n_in_ranks + 1);
+  nsx::LayoutOut out;
+  nsx::build_layout(in, n_virtual, order, schur_max_rows, out);
+  std::copy(out.perm2.begin(), out.perm2.end(), node_perm);
+  std::copy(out.perm1.begin(), out.perm1.end(), pnode_perm);
+  *n_ranks = (int32_t)out.u_ptr.size() - 1;
+  std::copy(out.u_ptr.begin(), out.u_ptr.end(), u_ptr);
+  std::copy(out.p_ptr.begin(), out.p_ptr.end(), p_ptr);
+  const std::vector<int32_t> &sb = out.schur_ptr.empty() ? out.p_ptr : out.schur_ptr;
+  *n_schur = (int32_t)sb.size() - 1;
+  std::copy(sb.begin(), sb.end(), schur_ptr);
+  if (colours) {
+    colours[0] = out.n_colours;
+    colours[1] = out.n_colours_p;
+  }
+  return 0;
 }

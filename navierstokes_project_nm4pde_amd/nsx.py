@@ -24,7 +24,9 @@ API = [
     "nsx_export_block", "nsx_schur_nnz", "nsx_schur_get", "nsx_scalar_graph_nnz", "nsx_scalar_graph", "nsx_ilu_get",
     "nsx_profile_enable", "nsx_profile_reset", "nsx_profile_count", "nsx_profile_get", "nsx_persistent_state", "nsx_comm_unique_id",
     "nsx_comm_init", "nsx_comm_init_callbacks", "nsx_comm_counters", "nsx_set_mesh_distributed", "nsx_set_force_faces", "nsx_compute_forces",
+    "nsx_set_internal_layout", "nsx_layout_info", "nsx_layout_get",
 ]
+FIRST_TOUCH, COLOUR, COLOUR_ALL = 0, 1, 2  # node order of nsx_set_internal_layout
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _f64p, C.c_int)
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(_f64p), C.POINTER(C.c_int),
@@ -64,6 +66,9 @@ def lib():
     L.nsx_set_mesh.argtypes = [vp, C.c_int, C.c_int, _i32p, _f64p, C.c_int, C.c_int]
     L.nsx_set_ranks.argtypes = [vp, C.c_int, _i32p, _i32p]
     L.nsx_set_schur_blocks.argtypes = [vp, C.c_int, _i32p]
+    L.nsx_set_internal_layout.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.nsx_layout_info.argtypes = [vp, C.POINTER(C.c_int)]
+    L.nsx_layout_get.argtypes = [vp, _i32p, _i32p, _i32p, _i32p, _i32p]
     for f in ("nsx_set_solution", "nsx_get_solution", "nsx_get_solution_ghosted", "nsx_get_rhs", "nsx_set_rhs"):
         getattr(L, f).argtypes = [vp, _f64p]
     L.nsx_assemble.argtypes = [vp, C.c_int]
@@ -145,10 +150,11 @@ def gloo_callbacks():
 class Nsx:
     """One device-side `NavierStokes` problem (a handle of libnsx)."""
 
-    def __init__(self, dofs, tables, nu, deltat, device=0, rank=0, world=1, comm="rccl"):
+    def __init__(self, dofs, tables, nu, deltat, device=0, rank=0, world=1, comm="rccl", layout=None):
         """world == 1: the whole problem on one GPU.  world > 1: this process holds rank `rank` of a run with one
         process per GPU (mesh partitioned with Mesh.partition(world, n_sub)); `comm` = "rccl" (needs an initialised
-        torch.distributed group to broadcast the unique id) or "callbacks" (host buffers over torch.distributed)."""
+        torch.distributed group to broadcast the unique id) or "callbacks" (host buffers over torch.distributed).
+        layout = (n_virtual_ranks, order, schur_max_rows): nsx_set_internal_layout, requested before the mesh is handed over."""
         L = lib()
         self.L = L
         self._h = C.c_void_p()
@@ -162,6 +168,8 @@ class Nsx:
         self.rank, self.world = rank, world
         N2, dN2, N1, w = _cd(tables.N2), _cd(tables.dN2), _cd(tables.N1), _cd(tables.weights)
         self._ck(L.nsx_set_tables(self._h, tables.n_q, tables.n_p2, tables.n_p1, _d(N2), _d(dN2), _d(N1), _d(w)))
+        if layout:
+            self.set_internal_layout(*layout)
         if world == 1:
             cd, cc = _ci(dofs.cell_dofs), _cd(dofs.cell_coords)
             self._ck(L.nsx_set_mesh(self._h, dofs.n_cells, dofs.dofs_per_cell, _i(cd), _d(cc), dofs.n_u, dofs.n_p))
@@ -240,6 +248,28 @@ class Nsx:
     def set_ranks(self, u_ptr, p_ptr):
         u_ptr, p_ptr = _ci(u_ptr), _ci(p_ptr)
         self._ck(self.L.nsx_set_ranks(self._h, len(u_ptr) - 1, _i(u_ptr), _i(p_ptr)))
+
+    def set_internal_layout(self, n_virtual_ranks, order=COLOUR, schur_max_rows=0):
+        self._ck(self.L.nsx_set_internal_layout(self._h, int(n_virtual_ranks), int(order), int(schur_max_rows)))
+
+    def layout_info(self):
+        info = (C.c_int * 5)()
+        self._ck(self.L.nsx_layout_info(self._h, info))
+        return {"on": bool(info[0]), "ranks": int(info[1]), "schur_blocks": int(info[2]), "colours": int(info[3]), "colours_p": int(info[4])}
+
+    def layout(self):
+        """node_perm / pnode_perm (owned caller node -> internal node, global ids), u_ptr / p_ptr / schur_ptr (nsx_layout_get)"""
+        info = self.layout_info()
+        if self.world == 1:
+            n2, n1 = self.n_u // self.dim, self.n_p
+        else:
+            n2 = int(self.view["gpu_u_ptr"][self.rank + 1] - self.view["gpu_u_ptr"][self.rank])
+            n1 = int(self.view["gpu_p_ptr"][self.rank + 1] - self.view["gpu_p_ptr"][self.rank])
+        out = {"node_perm": np.empty(n2, np.int32), "pnode_perm": np.empty(n1, np.int32), "u_ptr": np.empty(info["ranks"] + 1, np.int32),
+               "p_ptr": np.empty(info["ranks"] + 1, np.int32), "schur_ptr": np.empty(info["schur_blocks"] + 1, np.int32)}
+        self._ck(self.L.nsx_layout_get(self._h, *[_i(out[k]) for k in ("node_perm", "pnode_perm", "u_ptr", "p_ptr", "schur_ptr")]))
+        out.update(info)
+        return out
 
     def set_schur_blocks(self, p_ptr):
         p_ptr = _ci(p_ptr)

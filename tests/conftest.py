@@ -76,3 +76,22 @@ def rel_err(a, b):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     den = np.max(np.abs(b))
     return float(np.max(np.abs(a - b)) / (den if den > 0 else 1.0))
+
+
+def entry_err(a, b, rowptr, floor=1e-3, gfloor=1e-4):
+    """PER-ENTRY relative error of the values a against b on a CSR graph (SURVEY 8c pin 4: "every CSR value"): each entry is
+    measured against max(|b_ij|, floor * largest |b| of its row, gfloor * largest |b| of the matrix), so an entry 1e-4 of the
+    matrix norm that is 100 % wrong shows up as an error of order 1, where rel_err (global maximum norm) would report 1e-4.
+    The global floor keeps entries that vanish in exact arithmetic from being compared with themselves: whole rows of a
+    divergence block are sums of terms of the size of the largest entry that cancel to residues of 1e-19, and two correct
+    summation orders differ there by an ulp of the TERMS (3e-16 of the largest entry), not of the residue."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    if len(b) == 0:
+        return 0.0
+    counts = np.diff(rowptr)
+    rowmax = np.maximum.reduceat(np.abs(b), np.minimum(rowptr[:-1], len(b) - 1))
+    rowmax[counts == 0] = 0.0
+    den = np.maximum(np.maximum(np.abs(b), floor * np.repeat(rowmax, counts)), gfloor * np.max(np.abs(b)))
+    den[den == 0] = 1.0
+    return float(np.max(np.abs(a - b) / den))
