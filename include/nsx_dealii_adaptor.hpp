@@ -95,16 +95,22 @@ public:
   MPI_Comm comm = MPI_COMM_SELF;
   unsigned int rank = 0, world = 1;
   types::global_dof_index n_u = 0, n_p = 0;
+  bool state_reported = false;
 
   Binding() = default;
   Binding(const Binding &) = delete;
   ~Binding() { if (h) nsx_destroy(h); }
 
   // Called once at the end of NavierStokes::setup() (NavierStokes3D.cpp:157).  block_owned_dofs as built at :71-87.
-  // virtual_ranks > 1: split this rank's dof range into that many ILU(0) blocks; 1 keeps the
-  // reference's own layout (one Ifpack ILU per MPI rank, Preconditioners.hpp:215-216).
+  // The DoFHandler keeps deal.II's own numbering (distribute_dofs + component_wise, :58-69) and the run keeps its own rank count.
+  // virtual_ranks > 1 (default: ~85 velocity nodes per ILU(0) block, what the device kernels are laid out for): libnsx builds
+  // that many spatially compact, colour-ordered rank blocks INSIDE this rank's node range behind the C-ABI
+  // (nsx_set_internal_layout) -- nothing on the deal.II side is renumbered, every vector and dof list
+  // that crosses the boundary stays in the DoFHandler's numbering.  virtual_ranks = 1 keeps the reference's own layout (one
+  // Ifpack ILU per MPI rank, Preconditioners.hpp:215-216: exact, and orders of magnitude slower on a GPU).
   void setup(const DoFHandler<dim> &dh, const FiniteElement<dim> &fe, const Quadrature<dim> &quadrature, const double nu, const double deltat,
-             const std::vector<IndexSet> &block_owned_dofs, MPI_Comm communicator, const int device = -1, const int virtual_ranks = 1) {
+             const std::vector<IndexSet> &block_owned_dofs, MPI_Comm communicator, const int device = -1, int virtual_ranks = 0,
+             const int schur_max_rows = 96) {
     comm = communicator;
     rank = Utilities::MPI::this_mpi_process(comm);
     world = Utilities::MPI::n_mpi_processes(comm);
@@ -113,6 +119,9 @@ public:
     nsx_params prm{dim, device >= 0 ? device : int(rank % 8), nu, deltat};
     ck(nullptr, nsx_create(&prm, &h));
     set_tables(fe, quadrature);
+    if (virtual_ranks == 0) virtual_ranks = std::max<int>(1, int(block_owned_dofs[0].n_elements() / dim / 85));
+    // requested in front of the mesh: one set-up pass.  The layout is built from the cell tables handed over below.
+    if (virtual_ranks > 1) ck(h, nsx_set_internal_layout(h, virtual_ranks, NSX_ORDER_COLOUR, schur_max_rows));
     // this rank's owned cells: dof indices and vertex coordinates, exactly what the reference's cell loops ask for (:304,494)
     const unsigned int dpc = fe.dofs_per_cell;
     std::vector<int32_t> my_dofs;
@@ -133,14 +142,18 @@ public:
       setup_distributed(dpc, my_dofs, my_coords, mine_u, mine_p);
       ck(h, nsx_comm_init_callbacks(h, int(rank), int(world), allreduce_cb, exchange_cb, &comm));
     }
-    if (virtual_ranks > 1) {  // equal node counts per sub-block inside this rank's ranges (global node ids)
-      std::vector<int32_t> up(virtual_ranks + 1), pp(virtual_ranks + 1);
-      for (int r = 0; r <= virtual_ranks; ++r) {
-        up[r] = mine_u.first / dim + int(std::int64_t(mine_u.second - mine_u.first) / dim * r / virtual_ranks);
-        pp[r] = mine_p.first + int(std::int64_t(mine_p.second - mine_p.first) * r / virtual_ranks);
-      }
-      ck(h, nsx_set_ranks(h, virtual_ranks, up.data(), pp.data()));
-    }
+  }
+
+  // After the first solve_time_step: did the two single-launch kernels of the inner iteration (Gram-Schmidt sweep, Schur CG) run
+  // as such?  A handle whose grid was not co-resident (another process on the device) has fallen back to one launch per operation:
+  // correct, several times slower, and worth a line on the console.  Returns the number of fall-backs so far.
+  int report_persistent_state(ConditionalOStream &pcout) const {
+    int st[4] = {0, 0, 0, 0};
+    ck(h, nsx_persistent_state(h, st));
+    if (st[2] > 0 || (world == 1 && (!st[0] || !st[1])))
+      pcout << "nsx: persistent kernels: sweep " << st[0] << ", Schur CG " << st[1] << ", time-outs " << st[2]
+            << " -- running on the launch-per-operation path" << std::endl;
+    return st[2];
   }
 
   // ---- the three members -------------------------------------------------------------------------------------------
@@ -169,6 +182,10 @@ public:
     time_prec.push_back(st.t_prec);    // :572
     time_solve.push_back(st.t_solve);  // :577
     pcout << "Result:  " << st.outer_iterations << " GMRES iterations" << std::endl;  // :636
+    if (!state_reported) {
+      state_reported = true;
+      report_persistent_state(pcout);
+    }
     read_solution(solution_owned);
     solution = solution_owned;  // :638 (ghost import on the deal.II side for output() / compute_forces())
   }

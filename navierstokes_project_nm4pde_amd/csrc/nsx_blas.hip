@@ -648,11 +648,38 @@ __global__ __launch_bounds__(256) void k_mgs_blk(int n, int split, int gap, doub
 constexpr int MGS_ONE_VALS = 2 * (MGS_STEPS - 2) + 2;  // r_j, g_j (j < 30), |w|^2 before, |w|^2 after (second exchange)
 static_assert((size_t)MGS_ONE_VALS * MGS_MAX_WG + MGS_ONE_VALS <= MGS_BLK_REGION, "the one-exchange sweep shares the mailbox regions of k_mgs_blk");
 
-template <int E, int DMAX>
+// ---- the same sweep in a DISTRIBUTED run (DIST): the single exchange also crosses the ranks -------------------------------------
+// The reducers leave the LOCAL totals in ext.vals (one word each) and count themselves in at ext.arrive.  On the communication
+// stream the host has enqueued, right behind this launch:  k_ext_wait (spins until the count is complete)  ->  ncclAllReduce of
+// ext.vals over the ranks  ->  k_ext_release (stores this sweep's sequence number in ext.flag).  Every workgroup waits for that
+// flag instead of for the grid totals and goes on with the GLOBAL sums: the ten newest basis vectors stay in registers across
+// the collective, where the two-pass sweep (k_ls_dots / k_ls_update) reads the basis twice and pays two more launches.
+// Failure is agreed on by all ranks: a reducer whose mailbox wait timed out (or k_ext_wait, if the count never completes) raises
+// (All hand-offs are RELAXED agent-scope atomics behind an explicit s_waitcnt, like the mailboxes of nsx_grid.hpp: an acquire or a
+// release at agent scope makes the compiler invalidate / write back the XCD's whole L2 around the access -- polled by 448 workgroups
+// that doubled the time of the sweep's first phase: profiles/r04_ext_collective_timeline.txt.)
+// ext.vals[MGS_EXT_FAIL], the collective SUMS that word, and a non-zero sum makes every rank's grid end without touching w; the
+// hosts then all redo the sweep with the two-pass path.  The wait for the flag is bounded far above the other time-outs (a rank
+// that fails locally needs two of them before its collective goes out).  When the Gram formula for |w'|^2 is refused (the sweep
+// removed > 99 % of the norm: decided from the global sums, i.e. alike on every rank) the grid leaves the LOCAL sum of |w'|^2 in
+// ext.norm_out, does not normalise and reports "norm pending": the host all-reduces that word (the second collective).
+constexpr int MGS_EXT_VALS = 64, MGS_EXT_FAIL = 63;
+constexpr unsigned long long GX_EXT_TIMEOUT_TICKS = 1000000000ull;  // 10 s at 100 MHz
+struct MgsExt {
+  double *vals;              // [MGS_EXT_VALS] this sweep's buffer: local totals, then (after the collective) the global ones
+  double *vals_other;        // the other buffer: its failure word is cleared for the next sweep
+  unsigned int *arrive;      // reducers that have delivered, cumulative over all sweeps
+  unsigned long long *flag;  // sequence number of the last sweep whose collective is complete
+  double *norm_out;          // local |w'|^2 when the formula is refused
+};
+__device__ __forceinline__ double ext_ld(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ext_st(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <int E, int DMAX, bool DIST>
 __global__ __launch_bounds__(256) void k_mgs_one(int n, int split, int gap, double *__restrict__ w, MgsArgs V, int dim, double *__restrict__ gram,
                                                  unsigned long long *box, unsigned long long *box_next, int reset_words, double *__restrict__ scal_out,
                                                  int *err_host, unsigned long long *tail, int normalize, int consider, double *pub_vals,
-                                                 unsigned long long *pub_flag, unsigned long long seq, int drop_wg, double norm_guard) {
+                                                 unsigned long long *pub_flag, unsigned long long seq, int drop_wg, double norm_guard, MgsExt ext) {
   __shared__ double sh[4][MGS_ONE_VALS];   // per-wave sums of every value
   __shared__ double tot[MGS_ONE_VALS];     // grid totals
   __shared__ double G[MGS_STEPS][MGS_STEPS + 1], hc[MGS_STEPS];
@@ -666,6 +693,9 @@ __global__ __launch_bounds__(256) void k_mgs_one(int n, int split, int gap, doub
   unsigned long long *total = box + (size_t)MGS_ONE_VALS * MGS_MAX_WG, *total_next = box_next + (size_t)MGS_ONE_VALS * MGS_MAX_WG;
   for (int q = t; q < reset_words; q += T) box_next[q] = GX_EMPTY;
   if (wg == 0 && threadIdx.x < MGS_ONE_VALS) total_next[threadIdx.x] = GX_EMPTY;
+  if constexpr (DIST) {
+    if (wg == 0 && threadIdx.x < MGS_EXT_VALS) ext_st(ext.vals_other + threadIdx.x, 0.0);  // the next sweep's buffer (its failure word in particular)
+  }
   const int nvals = 2 * dim + 1;  // r_j at j, g_j at dim + j, |w|^2 at 2 dim
   // the older rows of the Gram matrix (written by the earlier sweeps of this cycle) are requested first and parked in registers:
   // read behind the exchange they were a trip through memory on the critical path of every workgroup
@@ -761,14 +791,43 @@ __global__ __launch_bounds__(256) void k_mgs_one(int n, int split, int gap, doub
     const double s_ = gx_wave_sum(a);
     if (lane == 0) sh[wave][0] = s_;
     __syncthreads();
-    if (threadIdx.x == 0 && !s_err) gx_post(total + v, (sh[0][0] + sh[1][0]) + (sh[2][0] + sh[3][0]));  // a total built on a timed-out mailbox never goes out
+    if constexpr (DIST) {
+      if (threadIdx.x == 0) {
+        if (!s_err) ext_st(ext.vals + v, (sh[0][0] + sh[1][0]) + (sh[2][0] + sh[3][0]));
+        else ext_st(ext.vals + MGS_EXT_FAIL, 1.0);  // summed over the ranks: everybody learns of it
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(ext.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // counted in either way: the collective must go out
+      }
+    } else {
+      if (threadIdx.x == 0 && !s_err) gx_post(total + v, (sh[0][0] + sh[1][0]) + (sh[2][0] + sh[3][0]));  // a total built on a timed-out mailbox never goes out
+    }
     __syncthreads();
   }
   MGS_STAMP();  // posted, and (reducers) totals out
   // ---- hop 2: everybody picks up the totals
-  for (int v = threadIdx.x; v < nvals; v += 256) {
-    tot[v] = gx_wait_value(total + v, &lerr);
-    if (lerr) s_err = 1;
+  if constexpr (DIST) {
+    if (threadIdx.x == 0) {  // the collective of this sweep is complete once the flag carries its sequence number
+      unsigned long long t0 = 0;
+      for (unsigned int spin = 1; __hip_atomic_load(ext.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seq; ++spin) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((spin & 255u) == 0) {
+          const unsigned long long now = wall_clock64();
+          if (t0 == 0) t0 = now;
+          else if (now - t0 > GX_EXT_TIMEOUT_TICKS) {
+            s_err = 1;
+            break;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    for (int v = threadIdx.x; v < nvals; v += 256) tot[v] = ext_ld(ext.vals + v);
+    if (threadIdx.x == 0 && ext_ld(ext.vals + MGS_EXT_FAIL) != 0.0) s_err = 1;  // some rank's grid was not complete
+  } else {
+    for (int v = threadIdx.x; v < nvals; v += 256) {
+      tot[v] = gx_wait_value(total + v, &lerr);
+      if (lerr) s_err = 1;
+    }
   }
   __syncthreads();
   MGS_STAMP();  // totals picked up
@@ -841,6 +900,7 @@ __global__ __launch_bounds__(256) void k_mgs_one(int n, int split, int gap, doub
     // the formula is a difference of numbers of size |w|^2: refuse it when less than 1 % of the norm is left
     double norm2 = s_norm2;
     const double w2 = tot[2 * dim];
+    bool norm_pending = false;
     if (!(norm2 > norm_guard * w2)) {  // uniform over the grid (same totals everywhere): a second exchange sums |w'|^2 itself
       double a = 0.0;
 #pragma unroll
@@ -859,18 +919,27 @@ __global__ __launch_bounds__(256) void k_mgs_one(int n, int split, int gap, doub
         const double sb = gx_wave_sum(b);
         if (lane == 0) sh[wave][1] = sb;
         __syncthreads();
-        if (threadIdx.x == 0 && !s_err) gx_post(total + v, (sh[0][1] + sh[1][1]) + (sh[2][1] + sh[3][1]));
+        if constexpr (DIST) {
+          // the local sum for the host's collective; a timed-out mailbox makes it NaN, which the host turns into the two-pass redo
+          if (threadIdx.x == 0) *ext.norm_out = s_err ? __longlong_as_double(0x7ff8000000000000ll) : (sh[0][1] + sh[1][1]) + (sh[2][1] + sh[3][1]);
+        } else {
+          if (threadIdx.x == 0 && !s_err) gx_post(total + v, (sh[0][1] + sh[1][1]) + (sh[2][1] + sh[3][1]));
+        }
       }
-      if (threadIdx.x == 0) {
-        const double x_ = gx_wait_value(total + v, &lerr);
-        if (lerr) s_err = 1;
-        s_norm2 = x_;
+      if constexpr (DIST) {
+        norm_pending = true;  // nobody waits: the sum travels through the host's all-reduce behind this launch
+      } else {
+        if (threadIdx.x == 0) {
+          const double x_ = gx_wait_value(total + v, &lerr);
+          if (lerr) s_err = 1;
+          s_norm2 = x_;
+        }
+        __syncthreads();
+        dead = s_err != 0;
+        norm2 = s_norm2;
       }
-      __syncthreads();
-      dead = s_err != 0;
-      norm2 = s_norm2;
     }
-    if (!dead && normalize) {  // vv *= 1. / s with s = sqrt(|vv|^2), skipped for s == 0 (SolverGMRES)
+    if (!dead && normalize && !norm_pending) {  // vv *= 1. / s with s = sqrt(|vv|^2), skipped for s == 0 (SolverGMRES)
       const double nrm = sqrt(norm2);
       const bool second_sweep = consider && !(nrm > 10. * sqrt(w2) * 1.4901161193847656e-08);
       if (nrm != 0.0 && !second_sweep) {
@@ -902,6 +971,10 @@ __global__ __launch_bounds__(256) void k_mgs_one(int n, int split, int gap, doub
       scal_out[dim + 1] = tot[2 * dim];
       __hip_atomic_store(pub_vals + dim, s_norm2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __hip_atomic_store(pub_vals + dim + 1, tot[2 * dim], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if constexpr (DIST) {  // 1: |w'|^2 is still rank-local (ext.norm_out) and w is not normalised
+        const double norm2_ = s_norm2, w2_ = tot[2 * dim];
+        __hip_atomic_store(pub_vals + dim + 2, !(norm2_ > norm_guard * w2_) ? 1.0 : 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -915,7 +988,10 @@ __global__ __launch_bounds__(256) void k_mgs_one(int n, int split, int gap, doub
   MGS_STAMP();  // stores issued
 }
 
-static const void *mgs_one_fn(int e) { return e <= 8 ? (const void *)k_mgs_one<8, 10> : (const void *)k_mgs_one<10, 8>; }
+static const void *mgs_one_fn(int e, bool dist = false) {
+  if (dist) return e <= 8 ? (const void *)k_mgs_one<8, 10, true> : (const void *)k_mgs_one<10, 8, true>;
+  return e <= 8 ? (const void *)k_mgs_one<8, 10, false> : (const void *)k_mgs_one<10, 8, false>;
+}
 
 template <int M>
 static const void *mgs_blk_fn(int e) {
@@ -956,6 +1032,20 @@ static void mgs_setup(nsx_handle *h) {
     if (getenv("NSX_DEBUG")) fprintf(stderr, "[nsx] mgs sweep (%d links per exchange, %d entries per thread): %d CUs x %d resident workgroups\n", h->mgs_links, es[k], cus, per_cu);
   }
   h->mgs_max_wg = h->mgs_max_wg_e[1];
+  // distributed instantiations: the collective's own kernels (RCCL's all-reduce, the two one-thread kernels around it) must find a
+  // place on the device WHILE the grid is resident and waiting for them: an eighth of the slots (at least 32) stays free
+  for (int k = 0; k < 2; ++k) {
+    int per_cu = 0;
+    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mgs_one_fn(es[k], true), 256, 0));
+    const int slots = per_cu * cus;
+    h->mgs_max_wg_dist[k] = std::max(0, std::min(MGS_MAX_WG, slots - std::max(32, slots / 8)));
+    if (getenv("NSX_MGS_MAXWG")) h->mgs_max_wg_dist[k] = std::max(1, std::min(h->mgs_max_wg_dist[k], atoi(getenv("NSX_MGS_MAXWG"))));
+  }
+  h->mgs_ext_vals.alloc(2 * MGS_EXT_VALS);
+  h->mgs_ext_vals.zero(h->stream);
+  h->mgs_ext_words.alloc(2);
+  h->mgs_ext_words.zero(h->stream);
+  h->mgs_ext_expected = 0;
 }
 
 void wait_published(nsx_handle *h, unsigned long long seq) {
@@ -976,6 +1066,13 @@ void wait_published(nsx_handle *h, unsigned long long seq) {
 // workgroups had already written their part of w (0: w is untouched and the sweep can simply be redone by the chain).
 static unsigned int mgs_recover(nsx_handle *h, unsigned long long failed_seq) {
   HIP_CHECK(hipStreamSynchronize(h->stream));
+  if (h->comm_stream) HIP_CHECK(hipStreamSynchronize(h->comm_stream));
+  if (h->mgs_ext_vals.p) {
+    h->mgs_ext_vals.zero(h->stream);
+    h->mgs_ext_words.zero(h->stream);
+    h->mgs_ext_expected = 0;
+  }
+  h->mgs_max_wg_dist[0] = h->mgs_max_wg_dist[1] = 0;
   std::vector<unsigned long long> tail(MGS_TAIL, 0);
   const size_t region = std::max(MGS_REGION, MGS_BLK_REGION);
   HIP_CHECK(hipMemcpy(tail.data(), h->mgs_box.p + 2 * region, MGS_TAIL * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -1167,19 +1264,30 @@ static void mgs_lowsync(nsx_handle *h, Span sp, double *w, int dim, double *cons
 bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int slot0, bool normalize, double *out,
            const std::function<void()> *after_launch, bool consider, double *gram) {
   const int n = sp.n;
-  if (!h->comm) mgs_setup(h);
+  // distributed run: the persistent sweep with the collective inside its exchange (k_mgs_one<.., true>) needs stream collectives
+  // (RCCL), the Gram cache and room on the device; NSX_MGS_DIST=0 keeps the two-pass sweep (mgs_lowsync)
+  if (h->comm && h->mgs_dist_state < 0) {  // decided once per handle, by all ranks together (comm_streams_concurrent)
+    const bool wanted = !(getenv("NSX_MGS_DIST") && atoi(getenv("NSX_MGS_DIST")) == 0);
+    h->mgs_dist_state = (wanted && comm_on_stream(h) && comm_streams_concurrent(h)) ? 1 : 0;
+  }
+  bool dist = h->comm && h->mgs_dist_state == 1 && !h->mgs_disabled && gram;
+  if (!h->comm || dist) mgs_setup(h);
+  dist = dist && h->mgs_links == 0 && 2 * dim + 1 < MGS_EXT_FAIL;
   // entries per thread: the smallest instantiation (8, 10, 20) whose resident grid covers the vector
   int nwg = 1, per_thread = 1 << 30, e_inst = 0;
   const int n_inst = h->mgs_links == 0 ? 2 : 3;  // the one-exchange sweep keeps a block of basis vectors in registers: 8 or 10 entries per thread
   for (int k = 0; k < n_inst && h->mgs_max_wg; ++k) {
     static const int es[3] = {8, 10, 20};
-    nwg = std::max(1, std::min(h->mgs_max_wg_e[k], cdiv(n, 256 * 4)));
+    const int cap = dist ? h->mgs_max_wg_dist[k] : h->mgs_max_wg_e[k];
+    if (cap <= 0) continue;
+    nwg = std::max(1, std::min(cap, cdiv(n, 256 * 4)));
     per_thread = cdiv(n, (int64_t)nwg * 256);
     e_inst = es[k];
     if (per_thread <= es[k]) break;
   }
   const int per_thread_max = h->mgs_links == 0 ? 10 : 20;
-  if (h->comm || h->mgs_max_wg == 0 || dim + 2 > MGS_STEPS || per_thread > per_thread_max || (h->mgs_links == 0 && !gram)) {
+  if (dist && (e_inst == 0 || per_thread > per_thread_max || dim + 2 > MGS_STEPS)) dist = false;
+  if ((h->comm && !dist) || h->mgs_max_wg == 0 || dim + 2 > MGS_STEPS || per_thread > per_thread_max || (h->mgs_links == 0 && !gram)) {
     // distributed solve: two collectives per sweep (mgs_lowsync); NSX_MGS_LOWSYNC=0: one launch + all-reduce per link, as the
     // reference's MPI run does.  Without a Gram cache (or too many vectors for it) the chain as well.
     if (h->ls_mode < 0) h->ls_mode = getenv("NSX_MGS_LOWSYNC") ? atoi(getenv("NSX_MGS_LOWSYNC")) : 2;  // read once per handle: 0 chain, 1 two collectives, 2 one
@@ -1211,14 +1319,29 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
     // beyond that — /opt/skills/guides/MI355X_MICROARCH.md, "Residency and cooperative launch" — and was removed.)  What makes the
     // sweep safe is the bounded wait: should a workgroup be missing (another stream or process holds compute units), the kernel
     // ends without writing w and the sweep is redone by the launch-per-link chain below.
-    const void *fn = mgs_fn(M, e_inst);
+    const void *fn = dist ? mgs_one_fn(e_inst, true) : mgs_fn(M, e_inst);
     if (M == 0) {
       // k_mgs_one: mailboxes box[v * nwg + wg] for the 2 dim + 1 values of the single exchange (+ 1 for the explicit norm)
       int reset_words = reset_wg * reset_steps;
       double *gram_ = gram;
       double guard_ = mgs_norm_guard();
-      void *args[] = {&n_, &split, &gap, &w, &V, &dim_, &gram_, &box, &box_next, &reset_words, &sout, &err, &tail, &norm_, &consider_, &pub_vals, &pub_flag, &seq_, &drop_wg, &guard_};
+      MgsExt ext{nullptr, nullptr, nullptr, nullptr, nullptr};
+      if (dist) {
+        ext.vals = h->mgs_ext_vals.p + (size_t)h->mgs_ext_parity * MGS_EXT_VALS;
+        ext.vals_other = h->mgs_ext_vals.p + (size_t)(1 - h->mgs_ext_parity) * MGS_EXT_VALS;
+        ext.flag = h->mgs_ext_words.p;
+        ext.arrive = (unsigned int *)(h->mgs_ext_words.p + 1);
+        ext.norm_out = h->scal.p + S_LS_NORM;
+      }
+      void *args[] = {&n_, &split, &gap, &w, &V, &dim_, &gram_, &box, &box_next, &reset_words, &sout, &err, &tail, &norm_, &consider_, &pub_vals, &pub_flag, &seq_, &drop_wg, &guard_, &ext};
       HIP_CHECK(hipLaunchKernel(fn, dim3(nwg), dim3(256), args, 0, h->stream));
+      if (dist) {
+        // the collective of this sweep, on the communication stream: it starts when the grid's 2 dim + 1 reducers have delivered
+        h->mgs_ext_expected += (unsigned int)(2 * dim + 1);
+        comm_ext_allreduce(h, ext.vals, MGS_EXT_VALS, MGS_EXT_FAIL, ext.arrive, h->mgs_ext_expected, ext.flag, seq);
+        h->mgs_ext_parity ^= 1;
+        h->slot_nb[S_LS_NORM] = 0;
+      }
       h->mgs_used_wg[h->mgs_parity] = 1;
       h->mgs_used_steps[h->mgs_parity] = (2 * dim + 2) * nwg;
     } else if (M == 1) {
@@ -1249,11 +1372,32 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
     if (committed != 0) NSX_THROW(NSX_ERR_HIP, "Gram-Schmidt sweep: %u workgroups had written w when another one timed out", committed);
     // what after_launch enqueued (the next operator application) used the unfinished w: its result is a temporary that the
     // caller recomputes when told that w was not normalised here
-    mgs_chain(h, sp, w, dim, vs, slot0, out, consider);
+    // (distributed: the failure word travelled through the collective, so every rank is here and redoes the sweep in two passes)
+    if (dist) {
+      if (h->ls_mode < 0) h->ls_mode = getenv("NSX_MGS_LOWSYNC") ? atoi(getenv("NSX_MGS_LOWSYNC")) : 2;
+      if (h->ls_mode && dim <= 31) mgs_lowsync(h, sp, w, dim, vs, slot0, out, consider, gram);
+      else mgs_chain(h, sp, w, dim, vs, slot0, out, consider);
+    } else {
+      mgs_chain(h, sp, w, dim, vs, slot0, out, consider);
+    }
     if (ran_ahead) h->mgs_redo_ahead = true;
     return false;
   }
   for (int i = 0; i <= dim + ((consider || h->mgs_links == 0) ? 1 : 0); ++i) out[i] = h->pub_host[slot0 + i];
+  if (dist && h->pub_host[slot0 + dim + 2] != 0.0) {
+    // the Gram formula for |w'|^2 was refused (alike on every rank): the grid left its local sum in the scalar slot and did not
+    // normalise; the second collective of the sweep sums it over the ranks.  (A NaN -- a mailbox of that sum timed out somewhere --
+    // is replaced by a plain dot product: w itself is complete.)
+    comm_allreduce_scalars(h, S_LS_NORM, 1);
+    double nrm2 = read_scalar(h, S_LS_NORM);
+    if (nrm2 != nrm2) {
+      v_dot(h, sp, w, w, S_LS_NORM);
+      nrm2 = read_scalar(h, S_LS_NORM);
+    }
+    out[dim] = nrm2;
+    if (ran_ahead) h->mgs_redo_ahead = true;  // what was enqueued behind the launch used the unnormalised w
+    return false;
+  }
   if (!normalize) return false;
   // the kernel's own decision, recomputed from the same two numbers
   return !consider || std::sqrt(out[dim]) > 10. * std::sqrt(out[dim + 1]) * 1.4901161193847656e-08;

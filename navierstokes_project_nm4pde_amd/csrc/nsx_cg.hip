@@ -454,7 +454,7 @@ void build_cg_plan(nsx_handle *h) {
   CgPlan &pl = h->cgplan;
   pl.ok = false;
   const IluSchedule &s = h->schedS;
-  if (h->dist || !s.dense || s.max_rows > CG_MAXB) return;
+  if (!s.dense || s.max_rows > CG_MAXB) return;  // (distributed handles use the plan through cg_schur_fused: columns may be ghosts)
   const Csr &g = h->gS.host;
   const std::vector<int32_t> &bptr = s.block_ptr_h;
   const int nb = s.n_blocks;
@@ -613,6 +613,241 @@ bool cg_schur_persistent(nsx_handle *h, double *x, const double *b, double rtol,
   // (block inverses resident in registers: read once per solve)
   // (operator resident in LDS: read once per solve, too)
   if (pe) pe->bytes += (lres ? 1.0 : (double)(*steps + 1)) * 10.0 * h->gS.nnz() + (double)(*steps + 1) * 48.0 * n + (pres ? 1.0 : (double)(*steps + 1)) * 8.0 * (double)s.dn_entries;
+  return true;
+}
+
+
+// ---- the same solve in a DISTRIBUTED run: TWO launches per iteration ----------------------------------------------------------------
+// With a communicator the solve cannot stay in one launch: the neighbours' d comes through a ghost exchange and the two sums of an
+// iteration through collectives the host enqueues.  The launch-per-operation solver (nsx_solve.hip: cg) pays five to six kernels
+// per iteration; here the persistent kernel's two phases are cut at its two exchanges and nothing else:
+//     k_cgd_A(it):  beta = g.h / g.h(old) from the all-reduced partial sums ; d = beta d(old) - h evaluated while gathering the
+//                   block's columns (ghost columns: the owner computed the same expression in its pack kernel and sent it) ;
+//                   hv = S d on the block's rows (slab stream) ; partial d.hv ; workgroup 0 publishes |g|^2 of the iteration before
+//     -- all-reduce of the d.hv partials --
+//     k_cgd_B(it):  alpha = g.h / d.hv ; x += alpha d ; g += alpha hv ; h = P_b g (explicit block inverse) ; partials g.g, g.h
+//     -- all-reduce of the g.g / g.h partials (one collective) --
+// Same lanes, same entries per lane and same block-local sums as k_cg_schur; the grid-wide sums are formed from one partial sum
+// per Schur block in block order (every rank pads to CGD_PARTS entries, the collective adds element-wise, every workgroup adds
+// the CGD_PARTS numbers in the same fixed order), so the result does not depend on timing -- and differs from the one-GPU kernel's
+// by the rounding of those sums.  The host waits for the residual published by k_cgd_A(it + 1), i.e. the next direction and product
+// are enqueued speculatively (wasted once per solve, by every rank alike: the collective sequences stay matched).
+constexpr int CGD_PARTS = 1024;
+enum { CGD_DH = 0, CGD_P0 = CGD_PARTS, CGD_BB = 3 * CGD_PARTS, CGD_P1 = 4 * CGD_PARTS, CGD_TOTAL = 6 * CGD_PARTS };  // P0 | BB contiguous: one collective after the set-up kernel
+
+// fixed-order sum of CGD_PARTS numbers by the 256 threads of the block (every thread gets it); sh: 4 doubles of its own per call site
+__device__ __forceinline__ double cgd_sum(const double *__restrict__ p, double *sh) {
+  double a = 0.0;
+#pragma unroll
+  for (int k = 0; k < CGD_PARTS / 256; ++k) a += p[threadIdx.x + 256 * k];
+  return gx_block_sum(a, sh);
+}
+__device__ __forceinline__ void cgd_dense_apply(const double *__restrict__ Pb, int nb, const double *gs, double *hs, int tid) {
+  const int grp = tid >> 4, lane = tid & 15;
+  for (int q = grp; q < nb; q += CG_NG) {
+    const double *prow = Pb + (size_t)q * nb;
+    double pv[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int j = lane + 16 * c;
+      pv[c] = j < nb ? prow[j] : 0.0;
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc += pv[c] * gs[lane + 16 * c];
+    acc = cg_group_sum<16>(acc);
+    if (lane == 0) hs[q] = acc;
+  }
+}
+
+// set-up: g = S x - b ; h = P g ; partials g.g, g.h (P0) and b.b (BB)
+__global__ __launch_bounds__(CG_THREADS) void k_cgd_init(const int32_t *__restrict__ bptr, const int32_t *__restrict__ u_ptr, const int32_t *__restrict__ u_cols,
+                                                   const int32_t *__restrict__ s_ptr, const double *__restrict__ sval, const uint16_t *__restrict__ slidx,
+                                                   const int32_t *__restrict__ sinfo, const int64_t *__restrict__ dn_off, const double *__restrict__ P,
+                                                   const double *__restrict__ b, const double *__restrict__ x, double *__restrict__ G, double *__restrict__ H,
+                                                   double *__restrict__ parts) {
+  __shared__ double gs[CG_MAXB], hs[CG_MAXB], hvs[CG_MAXB], xst[CG_MAX_UCOLS], sh[3][4];
+  const int wg = blockIdx.x, tid = threadIdx.x;
+  const int r0 = bptr[wg], nb = bptr[wg + 1] - r0, u0 = u_ptr[wg], nu = u_ptr[wg + 1] - u0;
+  const int s0 = s_ptr[3 * wg], s1 = s_ptr[3 * wg + 2];
+  const bool own = tid < nb;
+  double va[CG_PF];
+  int la[CG_PF];
+  cg_spmv_prefetch(s0, s1, sval, slidx, tid, va, la);
+  for (int k = tid; k < nu; k += CG_THREADS) xst[k] = x[u_cols[u0 + k]];
+  gs[tid] = 0.0;
+  const double bi = own ? b[r0 + tid] : 0.0;
+  __syncthreads();
+  cg_block_spmv(s0, s1, sval, slidx, sinfo, xst, hvs, tid, va, la);
+  __syncthreads();
+  if (own) {
+    gs[tid] = hvs[tid] - bi;
+    G[r0 + tid] = gs[tid];
+  }
+  __syncthreads();
+  cgd_dense_apply(P + dn_off[wg], nb, gs, hs, tid);
+  __syncthreads();
+  if (own) H[r0 + tid] = hs[tid];
+  const double gg = gx_block_sum(own ? gs[tid] * gs[tid] : 0.0, sh[0]);
+  const double gh = gx_block_sum(own ? gs[tid] * hs[tid] : 0.0, sh[1]);
+  const double bb = gx_block_sum(bi * bi, sh[2]);
+  if (tid == 0) {
+    parts[CGD_P0 + wg] = gg;
+    parts[CGD_P0 + CGD_PARTS + wg] = gh;
+    parts[CGD_BB + wg] = bb;
+  }
+}
+
+// the direction of iteration `it` for the nodes a neighbour needs (the communication stream's pack kernel): the owner's expression
+__global__ __launch_bounds__(256) void k_cgd_pack(int n_send, const int32_t *__restrict__ idx, int it, const double *__restrict__ parts, const double *__restrict__ H,
+                                                  const double *__restrict__ Dp, double *__restrict__ buf) {
+  __shared__ double sh[2][4];
+  double beta = 0.0;
+  if (it >= 2) {
+    const double *cur = parts + (((it - 1) & 1) ? CGD_P1 : CGD_P0), *old = parts + (((it - 1) & 1) ? CGD_P0 : CGD_P1);
+    beta = cgd_sum(cur + CGD_PARTS, sh[0]) / cgd_sum(old + CGD_PARTS, sh[1]);
+  }
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k < n_send) {
+    const int j = idx[k];
+    buf[k] = it == 1 ? -H[j] : __builtin_fma(beta, Dp[j], -H[j]);
+  }
+}
+
+__global__ __launch_bounds__(CG_THREADS) void k_cgd_A(const int32_t *__restrict__ bptr, const int32_t *__restrict__ u_ptr, const int32_t *__restrict__ u_cols,
+                                                const int32_t *__restrict__ s_ptr, const double *__restrict__ sval, const uint16_t *__restrict__ slidx,
+                                                const int32_t *__restrict__ sinfo, int n_own, int it, const double *__restrict__ parts, const double *__restrict__ H,
+                                                const double *__restrict__ Dp, double *Dc, double *__restrict__ Hv, double *__restrict__ part_dh, double *pub_vals,
+                                                unsigned long long *pub_flag, unsigned long long seq) {
+  __shared__ double ds[CG_MAXB], hvs[CG_MAXB], xst[CG_MAX_UCOLS], sh[4][4];
+  const int wg = blockIdx.x, tid = threadIdx.x;
+  const int r0 = bptr[wg], nb = bptr[wg + 1] - r0, u0 = u_ptr[wg], nu = u_ptr[wg + 1] - u0;
+  const int s0 = s_ptr[3 * wg], s1 = s_ptr[3 * wg + 2];
+  const bool own = tid < nb;
+  double va[CG_PF];
+  int la[CG_PF];
+  cg_spmv_prefetch(s0, s1, sval, slidx, tid, va, la);
+  // the sums of the iteration before (all-reduced partial sums): |g|^2 and g.h ; beta = g.h / g.h(old)
+  const double *cur = parts + (((it - 1) & 1) ? CGD_P1 : CGD_P0), *old = parts + (((it - 1) & 1) ? CGD_P0 : CGD_P1);
+  const double gg = cgd_sum(cur, sh[0]), gh = cgd_sum(cur + CGD_PARTS, sh[1]);
+  const double gh_old = it >= 2 ? cgd_sum(old + CGD_PARTS, sh[2]) : 1.0;
+  const double beta = it >= 2 ? gh / gh_old : 0.0;
+  if (wg == 0) {  // the residual of iteration it - 1 (and |b|^2 behind the set-up kernel) for the host's SolverControl::check
+    const double bb = it == 1 ? cgd_sum(parts + CGD_BB, sh[3]) : 0.0;
+    if (tid == 0) {
+      __hip_atomic_store(pub_vals + 0, gg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(pub_vals + 1, bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(pub_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  for (int k = tid; k < nu; k += CG_THREADS) {
+    const int j = u_cols[u0 + k];
+    xst[k] = j >= n_own ? Dc[j] : (it == 1 ? -H[j] : __builtin_fma(beta, Dp[j], -H[j]));  // ghost column: received ; owned: the owner's expression
+  }
+  if (own) {
+    const double dcur = it == 1 ? -H[r0 + tid] : __builtin_fma(beta, Dp[r0 + tid], -H[r0 + tid]);  // d = beta d - h (SolverCG: d.sadd(beta, -1., h))
+    ds[tid] = dcur;
+    Dc[r0 + tid] = dcur;
+  }
+  __syncthreads();
+  cg_block_spmv(s0, s1, sval, slidx, sinfo, xst, hvs, tid, va, la);
+  __syncthreads();
+  if (own) Hv[r0 + tid] = hvs[tid];
+  const double dh = gx_block_sum(own ? ds[tid] * hvs[tid] : 0.0, sh[3]);
+  if (tid == 0) part_dh[wg] = dh;
+}
+
+__global__ __launch_bounds__(CG_THREADS) void k_cgd_B(const int32_t *__restrict__ bptr, const int64_t *__restrict__ dn_off, const double *__restrict__ P, int it,
+                                                double *__restrict__ parts, double *__restrict__ x, double *__restrict__ G, double *__restrict__ H,
+                                                const double *__restrict__ Dc, const double *__restrict__ Hv) {
+  __shared__ double gs[CG_MAXB], hs[CG_MAXB], sh[4][4];
+  const int wg = blockIdx.x, tid = threadIdx.x;
+  const int r0 = bptr[wg], nb = bptr[wg + 1] - r0;
+  const bool own = tid < nb;
+  const double *prev = parts + (((it - 1) & 1) ? CGD_P1 : CGD_P0);
+  double *mine = parts + ((it & 1) ? CGD_P1 : CGD_P0);
+  const double dh = cgd_sum(parts + CGD_DH, sh[0]), gh = cgd_sum(prev + CGD_PARTS, sh[1]);
+  const double alpha = gh / dh;
+  gs[tid] = 0.0;
+  __syncthreads();
+  if (own) {
+    x[r0 + tid] += alpha * Dc[r0 + tid];
+    const double g = G[r0 + tid] + alpha * Hv[r0 + tid];
+    gs[tid] = g;
+    G[r0 + tid] = g;
+  }
+  __syncthreads();
+  cgd_dense_apply(P + dn_off[wg], nb, gs, hs, tid);
+  __syncthreads();
+  if (own) H[r0 + tid] = hs[tid];
+  const double gg = gx_block_sum(own ? gs[tid] * gs[tid] : 0.0, sh[2]);
+  const double ghn = gx_block_sum(own ? gs[tid] * hs[tid] : 0.0, sh[3]);
+  if (tid == 0) {
+    mine[wg] = gg;
+    mine[CGD_PARTS + wg] = ghn;
+  }
+}
+
+bool cg_schur_fused(nsx_handle *h, double *x, const double *b, double rtol, int maxiter, int *steps, double *last, int *status) {
+  const IluSchedule &s = h->schedS;
+  const CgPlan &pl = h->cgplan;
+  static const bool wanted = !(getenv("NSX_CG_FUSED") && atoi(getenv("NSX_CG_FUSED")) == 0);
+  if (!h->comm || !wanted || !s.dense || s.max_rows > CG_MAXB || !pl.ok || !pl.values_current || s.n_blocks > CGD_PARTS || CG_THREADS != 256) return false;
+  const int n = h->n_p, len = h->len_p, nblk = s.n_blocks;
+  if ((int)h->cgd_vec.n < 3 * n + 2 * len) {
+    h->cgd_vec.alloc((size_t)3 * n + 2 * len);
+    h->cgd_vec.zero(h->stream);
+  }
+  if (!h->cgd_parts.p) {
+    h->cgd_parts.alloc(CGD_TOTAL);
+    h->cgd_parts.zero(h->stream);  // entries beyond a rank's blocks stay 0 for good: the collectives add them element-wise
+  }
+  double *G = h->cgd_vec.p, *H = G + n, *Hv = H + n, *D[2] = {Hv + n, Hv + n + len}, *parts = h->cgd_parts.p;
+  double *pub_vals = h->pub_dev + S_CGP;
+  unsigned long long *pub_flag = (unsigned long long *)(h->pub_dev + N_SLOTS);
+  comm_halo_p(h, x);  // the ghost entries of the initial guess
+  {
+    LaunchScope ls(h, "cgd_init", 12.0 * h->gS.nnz() + 8.0 * (double)s.dn_entries + 40.0 * n);
+    hipLaunchKernelGGL(k_cgd_init, dim3(nblk), dim3(CG_THREADS), 0, h->stream, s.block_ptr.p, pl.u_ptr.p, pl.u_cols.p, pl.s_ptr.p, pl.s_val.p, pl.s_lidx.p,
+                       pl.s_info.p, s.dn_off.p, s.dn_P.p, b, x, G, H, parts);
+  }
+  comm_allreduce_partials(h, parts + CGD_P0, 3 * CGD_PARTS);
+  int it = 0, conv = 0;
+  double tol = 0.0, res = 0.0;
+  for (;;) {
+    const int nx = it + 1;
+    double *Dp = D[(nx + 1) & 1], *Dc = D[nx & 1];
+    // ghost entries of the next direction: the owners evaluate the same expression for the nodes their neighbours need
+    if (h->dist && !h->haloP.nbr.empty()) {
+      const std::function<void(hipStream_t, double *, const int32_t *, int)> packer = [&](hipStream_t st, double *buf, const int32_t *idx, int n_send) {
+        if (n_send) hipLaunchKernelGGL(k_cgd_pack, dim3(cdiv(n_send, 256)), dim3(256), 0, st, n_send, idx, nx, parts, H, Dp, buf);
+      };
+      comm_halo_begin(h, h->haloP, Dc, 1, &packer);
+      comm_halo_finish(h, h->haloP, Dc, 1);
+    }
+    const unsigned long long seq = ++h->pub_seq;
+    {
+      LaunchScope ls(h, "cgd_A", 10.0 * h->gS.nnz() + 40.0 * n);
+      hipLaunchKernelGGL(k_cgd_A, dim3(nblk), dim3(CG_THREADS), 0, h->stream, s.block_ptr.p, pl.u_ptr.p, pl.u_cols.p, pl.s_ptr.p, pl.s_val.p, pl.s_lidx.p, pl.s_info.p,
+                         n, nx, parts, H, Dp, Dc, Hv, parts + CGD_DH, pub_vals, pub_flag, seq);
+    }
+    comm_allreduce_partials(h, parts + CGD_DH, CGD_PARTS);
+    wait_published(h, seq);
+    if (it == 0) tol = rtol * std::sqrt(h->pub_host[S_CGP + 1]);  // solver_control_S(maxiter, 1e-2 * tmp.l2_norm())
+    res = std::sqrt(std::fabs(h->pub_host[S_CGP]));
+    conv = res <= tol ? 1 : ((it >= maxiter || res != res) ? 2 : 0);  // SolverControl::check
+    if (conv != 0) break;
+    it = nx;
+    {
+      LaunchScope ls(h, "cgd_B", 8.0 * (double)s.dn_entries + 56.0 * n);
+      hipLaunchKernelGGL(k_cgd_B, dim3(nblk), dim3(CG_THREADS), 0, h->stream, s.block_ptr.p, s.dn_off.p, s.dn_P.p, it, parts, x, G, H, Dc, Hv);
+    }
+    comm_allreduce_partials(h, parts + ((it & 1) ? CGD_P1 : CGD_P0), 2 * CGD_PARTS);
+  }
+  *steps = it;
+  *last = res;
+  *status = conv == 1 ? 0 : 1;
   return true;
 }
 

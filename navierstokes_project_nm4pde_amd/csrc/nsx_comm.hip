@@ -11,7 +11,7 @@
 //     N > 1 path be tested on a single GPU.
 #include <rccl/rccl.h>
 
-#include "nsx_internal.hpp"
+#include "nsx_grid.hpp"
 
 namespace nsx {
 
@@ -61,6 +61,103 @@ void comm_allreduce_partials(nsx_handle *h, double *partials, int count) {
   }
 }
 
+// ---- a collective INSIDE a persistent kernel's grid-wide exchange (nsx_blas.hip: k_mgs_one<.., true>) ---------------------------
+// The persistent grid runs on the compute stream and cannot call RCCL.  Its reducers leave the rank-local sums in `vals` and count
+// themselves in at `arrive`; on the COMMUNICATION stream, enqueued right behind the grid's launch: a one-thread kernel that spins
+// until the count is complete, the all-reduce, and a one-thread kernel that stores the sweep's sequence number in `flag`, which
+// every workgroup of the grid is waiting for.  All waits are bounded; a count that never completes raises vals[fail_word], which
+// the all-reduce sums, so every rank learns of it.
+__global__ void k_ext_wait(const unsigned int *arrive, unsigned int expected, double *vals, int fail_word) {
+  unsigned long long t0 = 0;
+  for (unsigned int spin = 1;; ++spin) {
+    if ((int)(__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - expected) >= 0) return;  // difference: the counter may wrap
+    __builtin_amdgcn_s_sleep(2);
+    if ((spin & 255u) == 0) {
+      const unsigned long long now = wall_clock64();
+      if (t0 == 0) t0 = now;
+      else if (now - t0 > 2 * GX_TIMEOUT_TICKS) {  // the grid behind it is not complete: tell every rank
+        __hip_atomic_store(vals + fail_word, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+      }
+    }
+  }
+}
+__global__ void k_ext_release(unsigned long long *flag, unsigned long long seq) {
+  __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+bool comm_on_stream(const nsx_handle *h) { return h->comm && h->comm->comm; }
+
+// A communication stream of the device's highest priority would take its hardware queue from another pool than the compute
+// stream's (the runtime shares hardware queues between streams of one priority once there are more streams than queues, and two
+// streams on one queue run in order -- the collective inside a persistent grid would wait for the grid that waits for it) ...
+static void ensure_comm_stream(nsx_handle *h) {
+  if (h->comm_stream) return;
+  int lo = 0, hi = 0;  // numerically lowest = highest priority
+  HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  // ... is what one would want.  Measured (bench.py --comm rccl1): with a communication stream of ANY priority other than the default
+  // every kernel of the compute stream runs three times slower (spmv_F 31 -> 92 us, with the highest and with the lowest priority
+  // alike), so the default priority it is; whether the two streams really run side by side is PROBED (comm_streams_concurrent)
+  // before the sweep relies on it.
+  const int prio = getenv("NSX_COMM_PRIO") ? atoi(getenv("NSX_COMM_PRIO")) : 0;  // 1 highest, 0 default, -1 lowest
+  HIP_CHECK(hipStreamCreateWithPriority(&h->comm_stream, hipStreamNonBlocking, prio > 0 ? hi : prio < 0 ? lo : (lo + hi) / 2));
+  HIP_CHECK(hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
+}
+
+__global__ void k_probe_wait(const unsigned long long *flag, int *seen) {
+  const unsigned long long t0 = wall_clock64();
+  *seen = 0;
+  for (;;) {
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+      *seen = 1;
+      return;
+    }
+    __builtin_amdgcn_s_sleep(8);
+    if (wall_clock64() - t0 > 2000000ull) return;  // 20 ms
+  }
+}
+// Do kernels of the communication stream run WHILE a kernel of the compute stream is waiting for them -- here, now, on every
+// rank?  A one-thread kernel on the compute stream waits (at most 20 ms) for a word that a one-thread kernel on the communication
+// stream stores; the ranks then take the minimum of their answers (one collective in the lifetime of a handle), so that all of
+// them use the collective-inside-the-grid sweep or none does.
+bool comm_streams_concurrent(nsx_handle *h) {
+  Comm *c = h->comm;
+  if (!c || !c->comm) return false;
+  ensure_comm_stream(h);
+  DevBuf<unsigned long long> word;
+  DevBuf<double> ans;
+  word.alloc(2);
+  ans.alloc(1);
+  word.zero(h->stream);
+  HIP_CHECK(hipStreamSynchronize(h->stream));
+  HIP_CHECK(hipStreamSynchronize(h->comm_stream));
+  hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(1), 0, h->stream, word.p, (int *)(word.p + 1));
+  hipLaunchKernelGGL(k_ext_release, dim3(1), dim3(1), 0, h->comm_stream, word.p, 1ull);
+  HIP_CHECK(hipStreamSynchronize(h->comm_stream));
+  HIP_CHECK(hipStreamSynchronize(h->stream));
+  int seen = 0;
+  HIP_CHECK(hipMemcpy(&seen, word.p + 1, sizeof(int), hipMemcpyDeviceToHost));
+  double v = seen ? 1.0 : 0.0;
+  HIP_CHECK(hipMemcpy(ans.p, &v, sizeof(double), hipMemcpyHostToDevice));
+  h->n_allreduce++;
+  NCCL_CHECK(ncclAllReduce(ans.p, ans.p, 1, ncclDouble, ncclMin, c->comm, h->stream));
+  HIP_CHECK(hipStreamSynchronize(h->stream));
+  HIP_CHECK(hipMemcpy(&v, ans.p, sizeof(double), hipMemcpyDeviceToHost));
+  if (getenv("NSX_DEBUG")) fprintf(stderr, "[nsx] communication stream runs beside a waiting compute kernel: here %d, on all ranks %d\n", seen, (int)(v > 0.5));
+  return v > 0.5;
+}
+
+void comm_ext_allreduce(nsx_handle *h, double *vals, int count, int fail_word, unsigned int *arrive, unsigned int expected, unsigned long long *flag,
+                        unsigned long long seq) {
+  Comm *c = h->comm;
+  if (!c || !c->comm) NSX_THROW(NSX_ERR_COMM, "internal: stream collective without an RCCL communicator");
+  ensure_comm_stream(h);
+  h->n_allreduce++;
+  hipLaunchKernelGGL(k_ext_wait, dim3(1), dim3(1), 0, h->comm_stream, arrive, expected, vals, fail_word);
+  NCCL_CHECK(ncclAllReduce(vals, vals, count, ncclDouble, ncclSum, c->comm, h->comm_stream));
+  hipLaunchKernelGGL(k_ext_release, dim3(1), dim3(1), 0, h->comm_stream, flag, seq);
+}
+
 template <int NC>
 __global__ void k_pack(int n, const int32_t *__restrict__ idx, const double *__restrict__ x, double *__restrict__ buf) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -80,21 +177,20 @@ static void launch_pack(nsx_handle *h, HaloPlan &p, const double *x, int ncomp, 
 // Refresh the ghost part of x (node-major, ncomp values per node) from the owners — the Epetra_Import of every vmult.
 // begin: on the communication stream, behind everything the compute stream holds so far: pack, then (RCCL) the grouped
 // send / receive straight into the ghost region, or (callbacks) the copy of the packed values to the host.
-void comm_halo_begin(nsx_handle *h, HaloPlan &p, double *x, int ncomp) {
+void comm_halo_begin(nsx_handle *h, HaloPlan &p, double *x, int ncomp,
+                     const std::function<void(hipStream_t, double *sendbuf, const int32_t *send_idx, int n_send)> *packer) {
   Comm *c = h->comm;
   const int nn = (int)p.nbr.size();
   if (nn == 0) return;
   if (!c || c->world == 1) NSX_THROW(NSX_ERR_COMM, "distributed mesh set but no communicator: call nsx_comm_init* first");
-  if (!h->comm_stream) {
-    HIP_CHECK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
-    HIP_CHECK(hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
-  }
+  ensure_comm_stream(h);
   if (!p.ev_done) HIP_CHECK(hipEventCreateWithFlags(&p.ev_done, hipEventDisableTiming));
   const int n_send = p.send_ptr[nn];
   h->n_halo++;
   HIP_CHECK(hipEventRecord(h->ev_ready, h->stream));
   HIP_CHECK(hipStreamWaitEvent(h->comm_stream, h->ev_ready, 0));
-  launch_pack(h, p, x, ncomp, n_send, h->comm_stream);
+  if (packer) (*packer)(h->comm_stream, p.sendbuf.p, p.send_idx.p, n_send);
+  else launch_pack(h, p, x, ncomp, n_send, h->comm_stream);
   double *ghost = x + (size_t)p.n_own * ncomp;
   if (c->comm) {
     NCCL_CHECK(ncclGroupStart());
@@ -189,6 +285,7 @@ int nsx_comm_init(nsx_handle *h, int rank, int world, const uint8_t id[128]) {
     ncclUniqueId u;
     memcpy(&u, id, 128);
     NCCL_CHECK(ncclCommInitRank(&h->comm->comm, world, u, rank));
+    h->mgs_dist_state = -1;  // a new communicator: the sweep's path is decided again, by all its ranks
   } catch (const nsx::Error &e) {
     h->err = e.msg;
     return e.code;
@@ -212,6 +309,7 @@ int nsx_comm_init_callbacks(nsx_handle *h, int rank, int world, nsx_allreduce_fn
   h->comm->allreduce = allreduce;
   h->comm->exchange = exchange;
   h->comm->ctx = ctx;
+  h->mgs_dist_state = -1;
   return NSX_OK;
 }
 

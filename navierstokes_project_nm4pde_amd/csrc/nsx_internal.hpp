@@ -294,6 +294,13 @@ struct nsx_handle {
   // distributed sweep with two collectives (mgs_lowsync): partial sums / all-reduced values / one 32 x 32 Gram matrix per GMRES nesting level
   nsx::DevBuf<double> ls_partial, ls_vals, ls_gram;
   int gmres_depth = 0, ls_mode = -1;
+  // the persistent sweep of a distributed run (k_mgs_one<.., true>): two value buffers used alternately, arrival counter, release flag
+  nsx::DevBuf<double> mgs_ext_vals;
+  nsx::DevBuf<unsigned long long> mgs_ext_words;  // [0] release flag, [1] arrival counter (32 bits used)
+  unsigned int mgs_ext_expected = 0;
+  int mgs_ext_parity = 0;
+  int mgs_dist_state = -1;           // -1 not decided yet, 0 two-pass sweep (mgs_lowsync), 1 the collective inside the persistent grid
+  int mgs_max_wg_dist[2] = {0, 0};   // resident-grid limits of the distributed instantiations (8 / 10 entries per thread), room left for the collective
   long long n_allreduce = 0, n_halo = 0;  // collectives issued (nsx_comm_counters)
   bool mgs_redo_ahead = false;         // a sweep fell back to the chain after work depending on its w had been enqueued
   // persistent Schur-complement CG (nsx_cg.hip: k_cg_schur): mailbox regions, work vectors (d double-buffered, h)
@@ -306,6 +313,7 @@ struct nsx_handle {
   bool cg_lds_resident = false;                        // ... and with the operator in LDS
   bool cg_variant_said = false;
   bool cg_disabled = false;
+  nsx::DevBuf<double> cgd_vec, cgd_parts;   // distributed Schur CG in two launches per iteration (cg_schur_fused): g, h, S d, d (double-buffered, with ghosts); partial sums
   // ---- force evaluation (compute_forces): obstacle faces + face-quadrature tables
   int ff_n = 0, ff_nq = 0;
   nsx::DevBuf<int32_t> ff_cells, ff_lf;
@@ -441,6 +449,7 @@ void wait_published(nsx_handle *h, unsigned long long seq);  // host waits for t
 void build_cg_plan(nsx_handle *h);   // with the ILU schedules
 void cg_pack_values(nsx_handle *h);  // after every schur_numeric
 bool cg_schur_persistent(nsx_handle *h, double *x, const double *b, double rtol, int maxiter, int *steps, double *last, int *status);
+bool cg_schur_fused(nsx_handle *h, double *x, const double *b, double rtol, int maxiter, int *steps, double *last, int *status);  // distributed runs: two launches per iteration
 void write_scalar(nsx_handle *h, int slot, double v);
 
 // solver (nsx_solve.hip)
@@ -454,10 +463,18 @@ void solve_time_step(nsx_handle *h, int type, double tol, double inner_rtol, int
 // comm (nsx_comm.hip)
 void comm_allreduce_scalars(nsx_handle *h, int slot0, int count);
 void comm_allreduce_partials(nsx_handle *h, double *partials, int count);  // in place, same count on every rank
+bool comm_streams_concurrent(nsx_handle *h);  // probe + agreement of all ranks (one collective): may a compute kernel wait for the communication stream?
+bool comm_on_stream(const nsx_handle *h);  // RCCL backend: collectives are stream operations (the callback backend runs them on the host)
+// the collective inside a persistent grid's exchange: on the communication stream wait for `arrive` to reach `expected`, all-reduce
+// vals[0..count), store `seq` in `flag` (nsx_comm.hip)
+void comm_ext_allreduce(nsx_handle *h, double *vals, int count, int fail_word, unsigned int *arrive, unsigned int expected, unsigned long long *flag,
+                        unsigned long long seq);
 void comm_halo(nsx_handle *h, HaloPlan &plan, double *x, int ncomp);
 // the same exchange in two halves: begin enqueues pack + send/receive on the communication stream (after everything the
 // compute stream holds so far), finish makes the compute stream wait for the ghosts; kernels launched in between overlap it
-void comm_halo_begin(nsx_handle *h, HaloPlan &plan, double *x, int ncomp);
+// packer (optional): fills the send buffer itself on the given stream (values that exist nowhere as a vector yet: the CG direction)
+void comm_halo_begin(nsx_handle *h, HaloPlan &plan, double *x, int ncomp,
+                     const std::function<void(hipStream_t, double *sendbuf, const int32_t *send_idx, int n_send)> *packer = nullptr);
 void comm_halo_finish(nsx_handle *h, HaloPlan &plan, double *x, int ncomp);
 void build_row_splits(nsx_handle *h);
 inline void comm_halo_u(nsx_handle *h, const double *x) { if (h->dist) comm_halo(h, h->haloU, const_cast<double *>(x), h->dim); }

@@ -183,7 +183,8 @@ class Nsx:
         self._ck(L.nsx_set_mesh_distributed(self._h, v["n_cells"], v["n_cells_layer1"], dofs.dofs_per_cell, _i(cd), _d(cc),
                                             dofs.n_u, dofs.n_p, world, rank, _i(arrs[0]), _i(arrs[1]), len(arrs[2]), _i(arrs[2]),
                                             _i(arrs[3]), _i(arrs[4]), _i(arrs[5]), _i(arrs[6])))
-        self.set_ranks(v["rank_u_ptr"], v["rank_p_ptr"])
+        if len(v["rank_u_ptr"]) > 2:  # one rank of the caller per GPU is the handle's default table
+            self.set_ranks(v["rank_u_ptr"], v["rank_p_ptr"])
         if comm == "callbacks":
             self._cb = gloo_callbacks()           # keep the CFUNCTYPE objects alive
             self._ck(L.nsx_comm_init_callbacks(self._h, rank, world, self._cb[0], self._cb[1], None))

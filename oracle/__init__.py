@@ -31,6 +31,13 @@ class Stats(C.Structure):
 _libs = {}
 
 
+def use_mt_library(path):
+    """bench.py's cpu_baseline leg: take the OpenMP build from `path` (the same source compiled on the benchmark host with
+    -O3 -march=native) instead of the portable in-tree build.  The parity tests never call this."""
+    global SO_MT
+    SO_MT = path
+
+
 def usable_cores():
     """CPU cores this process may actually use: scheduler affinity capped by the cgroup CPU quota (a GPU box hands a
     one-GPU job a share of its host cores, not all of them)."""
@@ -46,7 +53,7 @@ def usable_cores():
 
 
 def lib(mt=False):
-    so = SO_MT if mt else SO
+    so = SO_MT if mt else SO  # looked up at call time: use_mt_library may have redirected SO_MT
     if so not in _libs:
         if not os.path.exists(so):
             raise OSError("%s missing: run `make oracle`" % so)

@@ -95,3 +95,14 @@ def entry_err(a, b, rowptr, floor=1e-3, gfloor=1e-4):
     den = np.maximum(np.maximum(np.abs(b), floor * np.repeat(rowmax, counts)), gfloor * np.max(np.abs(b)))
     den[den == 0] = 1.0
     return float(np.max(np.abs(a - b) / den))
+
+
+def record(name, **values):
+    """Measured maxima of the parity suite (DESIGN.md section 5 quotes them): appended to gpurun_out/parity_maxima.jsonl when
+    that scratch directory exists (the GPU box's copy of the repository has it; nothing is written elsewhere)."""
+    import json
+    d = os.path.join(ROOT, "gpurun_out")
+    if not os.path.isdir(d):
+        return
+    with open(os.path.join(d, "parity_maxima.jsonl"), "a") as f:
+        f.write(json.dumps({"test": name, **{k: (float(v) if isinstance(v, (float, np.floating)) else v) for k, v in values.items()}}) + "\n")

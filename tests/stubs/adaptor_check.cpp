@@ -23,6 +23,11 @@ struct UsageSketch {
   nsx::Binding<dim> nsx_;
   std::map<dealii::types::global_dof_index, double> boundary_values;
   void setup() { nsx_.setup(dof_handler, *fe, *quadrature, 1e-3, 2e-4, block_owned_dofs, MPI_COMM_WORLD); }
+  // the MPI path with an explicit layout request: 512 virtual ranks inside every MPI rank's node range, Schur blocks of <= 96 rows
+  void setup_mpi_with_layout() { nsx_.setup(dof_handler, *fe, *quadrature, 1e-3, 2e-4, block_owned_dofs, MPI_COMM_WORLD, -1, 512, 96); }
+  // the reference's own layout (one ILU(0) block per MPI rank): no internal layout
+  void setup_reference_layout() { nsx_.setup(dof_handler, *fe, *quadrature, 1e-3, 2e-4, block_owned_dofs, MPI_COMM_WORLD, 0, 1); }
+  int health() { return nsx_.report_persistent_state(pcout); }
   void solve_head() { nsx_.write_solution(solution_owned); }
   void assemble() {
     nsx_.assemble(NSX_TEMAM);

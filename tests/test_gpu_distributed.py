@@ -94,6 +94,7 @@ def test_one_collective_per_gram_schmidt_sweep_equals_the_chain():
     out = []
     for flag in ("0", "1", "2"):
         os.environ["NSX_MGS_LOWSYNC"] = flag
+        os.environ["NSX_MGS_DIST"] = "0"   # the two-pass sweep itself (the default puts the collective inside the persistent grid: next test)
         try:
             dev = nsx.Nsx(dofs, tables, 1e-3, 2e-4)
             dev.comm_init_single()
@@ -106,6 +107,7 @@ def test_one_collective_per_gram_schmidt_sweep_equals_the_chain():
             dev.close()
         finally:
             os.environ.pop("NSX_MGS_LOWSYNC", None)
+            os.environ.pop("NSX_MGS_DIST", None)
     (s0, x0, c0, t0), (s1, x1, c1, t1), (s2, x2, c2, t2) = out
     for s, x in ((s1, x1), (s2, x2)):
         assert s0["status"] == 0 and s["status"] == 0
@@ -118,3 +120,45 @@ def test_one_collective_per_gram_schmidt_sweep_equals_the_chain():
     vectors = s2["outer_iterations"] + s2["inner_F_iterations"] + s2["inner_S_iterations"]
     assert c1[0] < 0.5 * c0[0], (c0, c1)
     assert c2[0] < 1.2 * vectors and c2[0] < 0.62 * c1[0], (c2, c1, vectors)
+
+
+def test_collective_inside_the_persistent_sweep_equals_the_two_pass_sweep():
+    """Distributed orthogonalisation, default path: the persistent one-exchange sweep with the all-reduce INSIDE its grid exchange
+    (k_mgs_one<.., true>: reducers -> k_ext_wait -> ncclAllReduce -> k_ext_release on the communication stream, the grid waits for
+    the flag with the ten newest basis vectors still in registers) against the two-pass sweep (NSX_MGS_DIST=0) and against a handle
+    without a communicator, through a 1-rank RCCL communicator.  Same iteration history, same solution, the same number of
+    collectives as the two-pass sweep (about one per Krylov vector), no time-out."""
+    from navierstokes_project_nm4pde_amd import nsx
+    from navierstokes_project_nm4pde_amd.frontend import DoFs, Mesh, Tables
+    from navierstokes_project_nm4pde_amd.problem import InletVelocity, cylinder_boundary_values
+    mesh = Mesh.cylinder(3, 2).partition(1, 8)
+    dofs, tables = DoFs(mesh, "colour"), Tables(3)
+    out = []
+    for comm, dist in ((False, None), (True, "0"), (True, "1")):
+        if dist is not None:
+            os.environ["NSX_MGS_DIST"] = dist
+        try:
+            dev = nsx.Nsx(dofs, tables, 1e-3, 2e-4)
+            if comm:
+                dev.comm_init_single()
+            dev.set_solution(np.zeros(dofs.n_dofs))
+            dev.assemble(nsx.TEMAM)
+            dev.apply_boundary_values(*cylinder_boundary_values(dofs, InletVelocity(3), 2e-4))
+            dev.profile(True)
+            st = dev.solve_time_step(nsx.ASIMPLE, tol_abs=1e-10, inner_rtol=1e-8)   # aSIMPLE: every inner solve is a GMRES
+            out.append((st, dev.solution_owned.copy(), dev.comm_counters(), dev.profile_table(), dev.persistent_state()))
+            dev.close()
+        finally:
+            os.environ.pop("NSX_MGS_DIST", None)
+    (s0, x0, c0, t0, p0), (s1, x1, c1, t1, p1), (s2, x2, c2, t2, p2) = out
+    assert s0["status"] == 0 and s1["status"] == 0 and s2["status"] == 0
+    for s, x in ((s1, x1), (s2, x2)):
+        for key in ("outer_iterations", "inner_F_iterations", "inner_S_iterations"):
+            assert abs(s0[key] - s[key]) <= max(1, 0.02 * s0[key]), key
+        assert np.abs(x0 - x).max() < 1e-9 * np.abs(x0).max()
+    # which kernels ran: two passes without the switch, ONE persistent launch per sweep with it
+    assert t1.get("mgs_dots", {}).get("launches", 0) > 0 and t1.get("mgs_sweep", {}).get("launches", 0) == 0
+    assert t2.get("mgs_sweep", {}).get("launches", 0) > 0 and t2.get("mgs_dots", {}).get("launches", 0) == 0
+    assert p2["fallbacks"] == 0 and p2["sweep_persistent"] and p2["dirty_mailbox_words"] == 0
+    # the collective count is the two-pass sweep's (+ the one agreement of the ranks on the path, once per handle)
+    assert abs(c2[0] - c1[0]) <= 2 + 0.01 * c1[0], (c1, c2)

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import Problem, rel_err
+from conftest import Problem, entry_err, record, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -10,6 +10,11 @@ pytestmark = pytest.mark.gpu
 # (a 6th entry overrides deltat: BASELINE.json configs[0] runs the 2D cylinder at deltat = 1e-3; the reference's main2D.cpp:21-22 uses 1e-2)
 CASES = [("cylinder", 3, 1, 1), ("cylinder", 3, 1, 6), ("cylinder", 2, 2, 1), ("cylinder", 2, 2, 5), ("cube", 3, 3, 1), ("cube", 3, 4, 3),
          ("cylinder", 3, 2, 24, "colour"), ("cylinder", 2, 2, 5, "colour"), ("cylinder", 2, 3, 4, "colour", 1e-3)]
+
+
+# asserted agreement of (velocity, pressure) after a full step at tol_abs = 1e-11 / inner_rtol = 1e-10, default 1e-10 each; the entries
+# below are the cases whose floor is higher, with the reason
+TIGHT_BOUND = {}
 
 
 def _bc(p, time):
@@ -20,12 +25,17 @@ def _bc(p, time):
     return cylinder_boundary_values(p.dofs, InletVelocity(p.dim, 2 if p.dim == 3 else 3), time)
 
 
-@pytest.fixture(scope="module", params=CASES, ids=lambda c: "%s%dd-l%d-r%d" % c[:4] + ("-" + c[4] if len(c) > 4 else "") + ("-dt%g" % c[5] if len(c) > 5 else ""))
+def _case_id(c):
+    return "%s%dd-l%d-r%d" % c[:4] + ("-" + c[4] if len(c) > 4 else "") + ("-dt%g" % c[5] if len(c) > 5 else "")
+
+
+@pytest.fixture(scope="module", params=CASES, ids=_case_id)
 def pair(request):
     kind, dim, level, nsub = request.param[:4]
     ordering = request.param[4] if len(request.param) > 4 else "first_touch"
     p = Problem(kind, dim, level, n_sub=nsub, nu=1e-2 if kind == "cube" else 1e-3,
                 deltat=request.param[5] if len(request.param) > 5 else (4e-4 if kind == "cube" else None), ordering=ordering)
+    p.case_id = _case_id(request.param)
     dev, ora = p.device(), p.oracle()
     u = p.smooth_velocity()
     dev.set_solution(u)
@@ -35,18 +45,30 @@ def pair(request):
     dev.close()
 
 
+def _matrix_check(p, dev, ora, which, block, name, tol=1e-12):
+    """every stored entry against the oracle's: the global maximum norm (1e-12) AND entry by entry (SURVEY 8c pin 4), each entry
+    measured against max(|b_ij|, 1e-3 of its row's largest, 1e-4 of the matrix' largest) -- conftest.entry_err"""
+    a, b = dev.export_block(which, block), ora.matrix(which, block)
+    assert rel_err(a, b) < tol, (name, block)
+    e = entry_err(a, b, p.dofs.reference_sparsity(3 if which == 4 else block)[0])
+    assert e < 100 * tol, (name, block, e)
+    return e
+
+
 def test_first_assembly_matches_oracle(pair):
     import navierstokes_project_nm4pde_amd.nsx as nsx
     p, dev, ora = pair
     flags = nsx.TEMAM | (nsx.DOUBLE_CONVECTION if p.mesh.bface_ids.max() > 3 else 0)
     dev.assemble(flags)
     ora.assemble(flags)
+    worst = 0.0
     for which, name in ((0, "system"), (1, "mass"), (2, "convection"), (3, "stiffness")):
-        assert rel_err(dev.export_block(which, 0), ora.matrix(which, 0)) < 1e-12, name
+        worst = max(worst, _matrix_check(p, dev, ora, which, 0, name))
     for block in (1, 2):
-        assert rel_err(dev.export_block(0, block), ora.matrix(0, block)) < 1e-12
-    assert rel_err(dev.export_block(4, 3), ora.matrix(4, 3)) < 1e-12
+        worst = max(worst, _matrix_check(p, dev, ora, 0, block, "system"))
+    worst = max(worst, _matrix_check(p, dev, ora, 4, 3, "pressure mass"))
     assert rel_err(dev.rhs, ora.rhs) < 1e-12
+    record("first_assembly", case=p.case_id, worst_entry_err=worst, rhs=rel_err(dev.rhs, ora.rhs))
 
 
 def test_dirichlet_matches_oracle(pair):
@@ -55,7 +77,7 @@ def test_dirichlet_matches_oracle(pair):
     dev.apply_boundary_values(bd, bv)
     ora.apply_boundary_values(bd, bv)
     for block in (0, 1, 2):
-        assert rel_err(dev.export_block(0, block), ora.matrix(0, block)) < 1e-12
+        _matrix_check(p, dev, ora, 0, block, "system after apply_boundary_values")
     assert rel_err(dev.rhs, ora.rhs) < 1e-12
     assert rel_err(dev.solution, ora.solution) < 1e-14
 
@@ -74,7 +96,7 @@ def test_preconditioner_initialize_matches_oracle(pair, prec):
     S_o = ora.schur()
     S_d = dev.schur()
     assert (S_o.indptr == S_d.indptr).all() and (S_o.indices == S_d.indices).all()
-    assert rel_err(S_d.data, S_o.data) < 1e-12
+    assert rel_err(S_d.data, S_o.data) < 1e-12 and entry_err(S_d.data, S_o.data, S_o.indptr) < 1e-10
     # ILU(0) factors: scalar layout vs the reference's padded layout (same-component entries carry the scalar factor)
     rp, ci, lu = dev.ilu(0)
     g0 = ora.graphs[0]
@@ -124,8 +146,16 @@ def test_time_steps_tight_tolerance(pair, prec):
         sd = dev.solve_time_step(prec, tol_abs=tol, inner_rtol=1e-10)
         so = ora.solve_time_step(prec, tol_abs=tol, inner_rtol=1e-10)
         assert sd["status"] == 0 and so["status"] == 0
-        scale = np.abs(ora.solution_owned).max()
-        assert np.abs(dev.solution_owned - ora.solution_owned).max() / scale < 1e-8
+        nu_ = p.dofs.n_u
+        xd, xo = dev.solution_owned, np.array(ora.solution_owned)
+        err_u = np.abs(xd[:nu_] - xo[:nu_]).max() / np.abs(xo[:nu_]).max()
+        err_p = np.abs(xd[nu_:] - xo[nu_:]).max() / np.abs(xo[nu_:]).max()
+        record("time_steps_tight", case=p.case_id, prec=prec, step=step, err_u=err_u, err_p=err_p, outer=sd["outer_iterations"])
+        # north_star: velocity and pressure within 1e-10 relative with both sides at tightened tolerances (pin 4).  Two
+        # solves that stop at a preconditioned residual of `tol` agree to about tol x the conditioning of the preconditioned
+        # operator: the bound is asserted per case in TIGHT_BOUND (measured maxima in DESIGN.md section 5)
+        bound_u, bound_p = TIGHT_BOUND.get((p.kind, p.dim, prec), (1e-10, 1e-10))
+        assert err_u < bound_u and err_p < bound_p, (err_u, err_p)
         # same algorithm, same arithmetic up to rounding: the iteration histories coincide (a restart more or less would
         # show up as tens of iterations)
         for key in ("outer_iterations", "inner_F_iterations", "inner_S_iterations"):

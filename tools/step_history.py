@@ -10,9 +10,13 @@ from navierstokes_project_nm4pde_amd import nsx  # noqa: E402
 from navierstokes_project_nm4pde_amd.problem import InletVelocity, cylinder_boundary_values  # noqa: E402
 
 n_steps = int(sys.argv[1]) if len(sys.argv) > 1 else 45
-mesh, dofs, tables = bench.build_problem(7, 4096, 1, "colour", balance=os.environ.get("NSX_BALANCE", "cells"))
-dev = nsx.Nsx(dofs, tables, 1e-3, 2e-4)
-dev.set_schur_blocks(bench.schur_block_table(dofs, 0))
+if os.environ.get("NSX_NUMBERING", "first_touch") == "first_touch":  # the bench default: deal.II's numbering handed over, layout built inside libnsx
+    mesh, dofs, tables = bench.build_problem(7, 4096, 1, "colour", numbering="first_touch", ranks_input=1)
+    dev = nsx.Nsx(dofs, tables, 1e-3, 2e-4, layout=(4096, nsx.COLOUR, bench.SCHUR_ROWS))
+else:
+    mesh, dofs, tables = bench.build_problem(7, 4096, 1, "colour", balance=os.environ.get("NSX_BALANCE", "cells"))
+    dev = nsx.Nsx(dofs, tables, 1e-3, 2e-4)
+    dev.set_schur_blocks(bench.schur_block_table(dofs, 0))
 inlet = InletVelocity(3)
 dev.set_solution(np.zeros(dofs.n_dofs))
 t = 0.0
