@@ -742,6 +742,14 @@ def main():
         out["gpu_over_best_cpu_all_cores"] = out["value"] / out["cpu_baseline"]["best_cpu"]["value"]
         out["gpu_over_cpu_all_cores"] = out["value"] / out["cpu_baseline"]["value"]
     emit(out)
+    if os.environ.get("NSX_DUMP_MAPS"):
+        # development aid (the round-2 abort inside exit() under rocprofv3): this process' mappings and the address of
+        # libc's exit().  Library mappings keep their relative distances from run to run of one command in one image, so the
+        # frames of a recorded stack can be translated by the difference of the two exit() addresses and looked up here.
+        import ctypes
+        with open(os.environ["NSX_DUMP_MAPS"], "w") as f:
+            f.write("exit %#x\n" % ctypes.cast(ctypes.CDLL(None).exit, ctypes.c_void_p).value)
+            f.write(open("/proc/self/maps").read())
     if world > 1:
         torch.distributed.destroy_process_group()
 

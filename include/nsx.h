@@ -207,6 +207,15 @@ int nsx_profile_get(nsx_handle *h, int i, const char **name, int64_t *launches, 
  * not empty in the region the next launch would use (0 on a healthy handle and after a recovered time-out). */
 int nsx_persistent_state(nsx_handle *h, int state[4]);
 
+/* SolverGMRES' orthogonalisation (deal.II's modified Gram-Schmidt add_and_dot chain inside every solver.solve of the path: reference
+ * NavierStokes3D.cpp:574, Preconditioners.hpp:173,273,288,382,405) on the caller's vectors, through the very sweep kernel the solvers
+ * use: vectors[m][n] (row k = vector k) -- vector 0 is normalised, vector k is orthogonalised against vectors 0..k-1 and normalised,
+ * in place.  coeffs[k * m + i] = h(i) of sweep k, norms2[k] = |w|^2 after sweep k (norms2[0]: |vector 0|^2 as it came).
+ * norm_guard: the sweep takes |w'|^2 from the basis' Gram matrix (|w|^2 - 2 h.r + h^T G h) while more than that fraction of |w|^2
+ * is left and sums it explicitly otherwise; 0 = always the formula, 1e300 = always the explicit sum, < 0 = the library's own (1e-2).
+ * A test hook for that formula; m <= 30. */
+int nsx_gram_schmidt_cycle(nsx_handle *h, int n, int m, double *vectors, double norm_guard, double *coeffs, double *norms2);
+
 /* ---- multi-GPU (one process per GPU, RCCL over xGMI) ---- */
 /* Replaces the MPI communicator inside Epetra (reference NavierStokes3D.hpp:93-94,102): MPI_Allreduce behind every
  * dot / norm, Epetra_Import behind every vmult and behind `solution = solution_owned` (NavierStokes3D.cpp:638). */

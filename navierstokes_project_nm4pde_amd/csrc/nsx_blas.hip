@@ -645,6 +645,17 @@ __global__ __launch_bounds__(256) void k_mgs_blk(int n, int split, int gap, doub
 // The exchange is two hops like the others: value v is summed over the workgroups' mailboxes by workgroup v % nwg (the 2 dim + 1
 // sums are spread over the grid instead of queueing in workgroup 0), the totals are picked up by everybody.
 // Mailboxes: box[v * nwg + wg], totals behind them at box[MGS_ONE_VALS * MGS_MAX_WG + v].
+// Basis vectors beyond the block kept in registers are read TWICE by a sweep (dot pass, update pass).  The register-resident ones
+// are streamed with non-temporal loads (-DNSX_NT & 1: they must not evict F and the ILU factors from the 256-MiB Infinity Cache,
+// profiles/r02_cache_policy_and_links.txt); the older ones take the default policy, so that the update pass finds in that cache what
+// the dot pass brought in (-DNSX_MGS_OLD_NT=1: non-temporal as well, rounds 2-3).
+#ifndef NSX_MGS_OLD_NT
+#define NSX_MGS_OLD_NT 0
+#endif
+__device__ __forceinline__ double ld_twice(const double *p) {
+  if constexpr (NSX_MGS_OLD_NT != 0) return ld_stream<1>(p);
+  else return *p;
+}
 constexpr int MGS_ONE_VALS = 2 * (MGS_STEPS - 2) + 2;  // r_j, g_j (j < 30), |w|^2 before, |w|^2 after (second exchange)
 static_assert((size_t)MGS_ONE_VALS * MGS_MAX_WG + MGS_ONE_VALS <= MGS_BLK_REGION, "the one-exchange sweep shares the mailbox regions of k_mgs_blk");
 
@@ -751,7 +762,7 @@ __global__ __launch_bounds__(256) void k_mgs_one(int n, int split, int gap, doub
     double ar = 0.0, ag = 0.0;
 #pragma unroll
     for (int k = 0; k < E; ++k) {
-      const double x_ = idx[k] >= 0 ? ld_stream<1>(vp + idx[k]) : 0.0;
+      const double x_ = idx[k] >= 0 ? ld_twice(vp + idx[k]) : 0.0;
       ar += wv[k] * x_;
       ag += vl[k] * x_;
     }
@@ -834,7 +845,7 @@ __global__ __launch_bounds__(256) void k_mgs_one(int n, int split, int gap, doub
   bool dead = s_err != 0;
   double xo[E];  // entries of the next streamed (older) vector of the update below
 #pragma unroll
-  for (int k = 0; k < E; ++k) xo[k] = (!dead && j_keep > 0 && idx[k] >= 0) ? ld_stream<1>(V.v[0] + idx[k]) : 0.0;
+  for (int k = 0; k < E; ++k) xo[k] = (!dead && j_keep > 0 && idx[k] >= 0) ? ld_twice(V.v[0] + idx[k]) : 0.0;
   if (!dead) {
     // Gram matrix of the basis: older rows parked in G before the exchange, the new row from this exchange; then h by forward substitution and the
     // norm after the sweep, one wave, lane j = link j
@@ -882,7 +893,7 @@ __global__ __launch_bounds__(256) void k_mgs_one(int n, int split, int gap, doub
     for (int j = 0; j < j_keep; ++j) {
       double xn[E];
 #pragma unroll
-      for (int k = 0; k < E; ++k) xn[k] = (j + 1 < j_keep && idx[k] >= 0) ? ld_stream<1>(V.v[j + 1] + idx[k]) : 0.0;
+      for (int k = 0; k < E; ++k) xn[k] = (j + 1 < j_keep && idx[k] >= 0) ? ld_twice(V.v[j + 1] + idx[k]) : 0.0;
       const double alpha = -1.0 * hc[j];
 #pragma unroll
       for (int k = 0; k < E; ++k)
@@ -1220,9 +1231,9 @@ __global__ __launch_bounds__(256) void k_ls_update(int n, int split, int gap, do
 // |w'|^2 = |w|^2 - 2 h.r + h^T G h is a difference of numbers of size |w|^2: its relative error is about eps * dim * |w|^2 / |w'|^2.
 // It is accepted when |w'|^2 > guard * |w|^2 (default 1e-2: the norm of the new basis vector is then good to ~1e-13, two orders
 // below the tightest tolerance the parity tests solve to); otherwise |w'|^2 is summed over the vector (one more exchange / collective).
-static double mgs_norm_guard() {
+static double mgs_norm_guard(const nsx_handle *h) {
   static const double g = getenv("NSX_MGS_NORM_GUARD") ? atof(getenv("NSX_MGS_NORM_GUARD")) : 1e-2;
-  return g;
+  return h->mgs_guard_override >= 0.0 ? h->mgs_guard_override : g;  // the override: nsx_gram_schmidt_cycle (tests)
 }
 
 static void mgs_lowsync(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int slot0, double *out, bool consider, double *gram) {
@@ -1251,7 +1262,7 @@ static void mgs_lowsync(nsx_handle *h, Span sp, double *w, int dim, double *cons
   double tmp[N_TMP_MAX + 2];
   read_scalars(h, slot0, dim + 2, tmp);
   // one collective: |w_after|^2 from the Gram algebra, unless the sweep removed more than 99 % of the norm (cancellation)
-  const bool by_formula = h->ls_mode >= 2 && tmp[dim] > mgs_norm_guard() * tmp[dim + 1];
+  const bool by_formula = h->ls_mode >= 2 && tmp[dim] > mgs_norm_guard(h) * tmp[dim + 1];
   if (!by_formula) {
     after_reduction(h, S_LS_NORM, nb);  // collective 2: |w|^2 summed over the vector
     tmp[dim] = read_scalar(h, S_LS_NORM);
@@ -1324,7 +1335,7 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
       // k_mgs_one: mailboxes box[v * nwg + wg] for the 2 dim + 1 values of the single exchange (+ 1 for the explicit norm)
       int reset_words = reset_wg * reset_steps;
       double *gram_ = gram;
-      double guard_ = mgs_norm_guard();
+      double guard_ = mgs_norm_guard(h);
       MgsExt ext{nullptr, nullptr, nullptr, nullptr, nullptr};
       if (dist) {
         ext.vals = h->mgs_ext_vals.p + (size_t)h->mgs_ext_parity * MGS_EXT_VALS;
@@ -1553,6 +1564,48 @@ static int mgs_dirty_words(nsx_handle *h) {
 }
 
 }  // namespace nsx
+
+// One GMRES cycle's worth of orthogonalisation on the caller's vectors, through the very sweep the solvers use (v_mgs with the
+// basis' Gram matrix kept on the device): vectors[0] is normalised, vectors[k] is swept against the k vectors in front of it and
+// normalised.  norm_guard >= 0 replaces the threshold below which the Gram formula for |w'|^2 is refused (0: always the formula,
+// 1e300: always the explicitly summed norm); < 0 keeps the handle's.  For the tests of that formula (tests/test_gpu_errors.py).
+extern "C" int nsx_gram_schmidt_cycle(nsx_handle *h, int n, int m, double *vectors, double norm_guard, double *coeffs, double *norms2) {
+  if (!h || !vectors || !coeffs || !norms2 || n < 1 || m < 1 || m > 30) return NSX_ERR_ARG;
+  try {
+    HIP_CHECK(hipSetDevice(h->prm.device));
+    std::vector<nsx::DevBuf<double>> v(m);
+    for (int k = 0; k < m; ++k) v[k].upload(vectors + (size_t)k * n, n, h->stream);
+    if (!h->ls_gram.p) {
+      h->ls_gram.alloc(4 * 1024);
+      h->ls_gram.zero(h->stream);
+    }
+    const double keep = h->mgs_guard_override;
+    h->mgs_guard_override = norm_guard;
+    try {
+      const nsx::Span sp(n);
+      nsx::v_dot(h, sp, v[0].p, v[0].p, 40);
+      norms2[0] = nsx::read_scalar(h, 40);
+      nsx::v_scale(h, sp, v[0].p, 1.0 / std::sqrt(norms2[0]));
+      for (int k = 1; k < m; ++k) {
+        double *vs[32], out[34];
+        for (int i = 0; i < k; ++i) vs[i] = v[i].p;
+        const bool normalized = nsx::v_mgs(h, sp, v[k].p, k, vs, 8, true, out, nullptr, false, h->ls_gram.p);
+        for (int i = 0; i < k; ++i) coeffs[(size_t)k * m + i] = out[i];
+        norms2[k] = out[k];
+        if (!normalized && out[k] > 0.0) nsx::v_scale(h, sp, v[k].p, 1.0 / std::sqrt(out[k]));
+      }
+    } catch (...) {
+      h->mgs_guard_override = keep;
+      throw;
+    }
+    h->mgs_guard_override = keep;
+    for (int k = 0; k < m; ++k) v[k].download(vectors + (size_t)k * n, n, h->stream);
+  } catch (const nsx::Error &e) {
+    h->err = e.msg;
+    return e.code;
+  }
+  return NSX_OK;
+}
 
 extern "C" int nsx_persistent_state(nsx_handle *h, int state[4]) {
   if (!h || !state) return NSX_ERR_ARG;

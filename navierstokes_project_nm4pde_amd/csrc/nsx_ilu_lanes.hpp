@@ -80,7 +80,9 @@ __device__ __forceinline__ void lane_tick(const LaneSlot<E> &s, const LaneSlot<E
   __builtin_amdgcn_wave_barrier();  // compiler only: the next tick's reads stay behind this write
 }
 
-// sa .. sb: the slabs of one sweep of this wave, a multiple of ILU_STREAM_ALIGN = 8 (host/ilu_stream.hpp pads with idle slabs).
+// sa .. sb: the slabs of one sweep of this wave, a multiple of ILU_STREAM_ALIGN = 4 (host/ilu_stream.hpp pads with idle slabs): blocks
+// of PF = 8 ticks and, if four slabs are left at the END of the sweep, one block of four (the register sets and the prefetch depth
+// stay at eight slabs: the last load then reaches four slabs into whatever follows in the stream, which is never executed).
 // The stream is padded behind its end (ILU_STREAM_PAD slabs): prefetching needs no bounds check.  Uniform base + 32-bit lane
 // offset: the loads take the scalar-base addressing form (no 64-bit vector address arithmetic per load).
 template <int E, int PF>
@@ -123,14 +125,31 @@ __device__ __forceinline__ void lane_sweep(LaneSlot<E> (&A)[PF], int sa, int sb,
       lane_tick<NCOMP, E>(S[k + 1], k + 2 < PF ? S[k + 2 < PF ? k + 2 : 0] : (more_ ? SNEXT : idle), scratch, acc, o1, o0); \
     }                                                                                          \
   }
+  // the sweep's last PF / 2 ticks (PF = 8 only: with PF = 4 a block is the alignment unit)
+#define NSX_USE_HALF(S)                                                                        \
+  {                                                                                            \
+    _Pragma("unroll") for (int k = 0; k < PF / 2; k += 2) {                                    \
+      lane_tick<NCOMP, E>(S[k], S[k + 1], scratch, acc, o0, o1);                               \
+      lane_tick<NCOMP, E>(S[k + 1], k + 2 < PF / 2 ? S[k + 2 < PF / 2 ? k + 2 : 0] : idle, scratch, acc, o1, o0); \
+    }                                                                                          \
+  }
   lane_read<NCOMP, E>(A[0], o0);
   for (int s0 = sa; s0 < sb; s0 += 2 * PF) {
     lane_load<E, PF>(B, s0 + PF, meta, val, lane);
+    if (PF == 8 && sb - s0 < PF) {
+      NSX_USE_HALF(A)
+      break;
+    }
     NSX_USE(A, B[0], s0)
     if (s0 + PF >= sb) break;
     lane_load<E, PF>(A, s0 + 2 * PF, meta, val, lane);
+    if (PF == 8 && sb - (s0 + PF) < PF) {
+      NSX_USE_HALF(B)
+      break;
+    }
     NSX_USE(B, A[0], s0 + PF)
   }
+#undef NSX_USE_HALF
 #undef NSX_USE
 }
 

@@ -289,6 +289,7 @@ struct nsx_handle {
   int mgs_max_wg_e[3] = {0, 0, 0};     // resident-grid limit of the 8 / 10 / 20 entries-per-thread instantiations
   int mgs_links = 2;                   // links of the add_and_dot chain per grid-wide exchange (NSX_MGS_LINKS; 1 = k_mgs)
   bool mgs_disabled = false;
+  double mgs_guard_override = -1.0;    // >= 0: threshold of the Gram formula for |w'|^2 for the duration of nsx_gram_schmidt_cycle
   int gx_drop_wg = -1;                 // NSX_GX_DROP_WG (fault injection, tests): this workgroup of a persistent grid never posts its sums
   int n_persistent_fallbacks = 0;      // persistent kernels that timed out on this handle (nsx_solve_stats::persistent_fallbacks)
   // distributed sweep with two collectives (mgs_lowsync): partial sums / all-reduced values / one 32 x 32 Gram matrix per GMRES nesting level

@@ -196,8 +196,35 @@ void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> 
   s.blk_lvl_off.upload(off_f, h->stream);
   s.blk_lvl_off_b.upload(off_b, h->stream);
 
-  // ---- the packed stream of the solve kernel (host/ilu_stream.hpp, k_ilu_solve_lanes)
-  {
+  // ---- explicit block inverses.  Worth it when the blocks are few, small and deep: the dense matrices of all blocks
+  // together (sum n_b^2) must not cost more traffic than the chain of the sparse sweep costs time.  Used for the Schur
+  // matrix (one component, ~100-row blocks with ~95 dependency levels); the velocity blocks stay sparse.
+  s.dense = false;
+  if (allow_dense && ncomp == 1) {
+    std::vector<int64_t> off(nb + 1, 0);
+    for (int b = 0; b < nb; ++b) {
+      const int64_t n = bptr[b + 1] - bptr[b];
+      off[b + 1] = off[b] + n * n;
+    }
+    const int64_t limit = getenv("NSX_DENSE_MAX") ? atoll(getenv("NSX_DENSE_MAX")) : ((int64_t)32 << 20);  // entries (256 MB)
+    if (off[nb] > 0 && off[nb] <= limit && s.max_rows <= 4096) {
+      s.dense = true;
+      s.dn_entries = off[nb];
+      s.dn_off.upload(off, h->stream);
+      s.dn_P.alloc((size_t)off[nb]);
+      if (getenv("NSX_DEBUG")) fprintf(stderr, "[nsx] ilu schedule: explicit block inverses, %lld entries (%.1f MB)\n", (long long)off[nb], 8e-6 * off[nb]);
+    }
+  }
+  // ---- the packed stream of the solve kernel (host/ilu_stream.hpp, k_ilu_solve_lanes) -- unless it would never be used: the
+  // schedule is served by the explicit block inverses above (the Schur matrix), or its largest block alone does not fit the 16-bit
+  // LDS addresses of the stream (few large ranks: up to 4096-row blocks run through the workgroup-per-block kernel).  Building it
+  // is list scheduling per wave plus an upload the size of the factor; slot_of stays null, so the factorisation kernels skip the
+  // stream writes.
+  const bool stream_fits = ((size_t)s.max_rows + 64) * sizeof(double) * ncomp <= 65536;
+  s.n_waves = 0;
+  s.n_slabs = 0;
+  s.stream_ncomp = 0;
+  if (!s.dense && stream_fits) {
     IluStream st;
     const int ept = getenv("NSX_ILU_EPT") ? std::max(1, std::min(4, atoi(getenv("NSX_ILU_EPT")))) : 2;
     build_ilu_stream(g, bptr, std::max(1, blocks_per_wave), ncomp, 2, st, ept);
@@ -229,25 +256,6 @@ void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> 
     s.pk_dinv.alloc(g.n_rows);
   }
 
-  // ---- explicit block inverses.  Worth it when the blocks are few, small and deep: the dense matrices of all blocks
-  // together (sum n_b^2) must not cost more traffic than the chain of the sparse sweep costs time.  Used for the Schur
-  // matrix (one component, ~100-row blocks with ~95 dependency levels); the velocity blocks stay sparse.
-  s.dense = false;
-  if (allow_dense) {
-    std::vector<int64_t> off(nb + 1, 0);
-    for (int b = 0; b < nb; ++b) {
-      const int64_t n = bptr[b + 1] - bptr[b];
-      off[b + 1] = off[b] + n * n;
-    }
-    const int64_t limit = getenv("NSX_DENSE_MAX") ? atoll(getenv("NSX_DENSE_MAX")) : ((int64_t)32 << 20);  // entries (256 MB)
-    if (off[nb] > 0 && off[nb] <= limit && s.max_rows <= 4096) {
-      s.dense = true;
-      s.dn_entries = off[nb];
-      s.dn_off.upload(off, h->stream);
-      s.dn_P.alloc((size_t)off[nb]);
-      if (getenv("NSX_DEBUG")) fprintf(stderr, "[nsx] ilu schedule: explicit block inverses, %lld entries (%.1f MB)\n", (long long)off[nb], 8e-6 * off[nb]);
-    }
-  }
 }
 
 // chunks = [bounds[c], bounds[c+1])

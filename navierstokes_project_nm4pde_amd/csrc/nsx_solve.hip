@@ -508,6 +508,7 @@ void solve_time_step(nsx_handle *h, int type, double tol, double inner_rtol, int
   comm_halo_u(h, h->sol.p);
   comm_halo_p(h, h->sol.p + h->off_p);
   HIP_CHECK(hipStreamSynchronize(h->stream));
+  ilu_check(h);  // a triangular-solve kernel that refused to run (nsx_sparse.hip: k_ilu_solve_lanes) fails the call
   st->t_solve = now_s() - t0;
   st->outer_iterations = r.steps;
   st->final_residual = r.last;
@@ -576,6 +577,7 @@ int nsx_prec_vmult(nsx_handle *h, int prec_type, double inner_rtol, int inner_ma
     nsx::prec_vmult(h, prec_type, inner_rtol, inner_maxiter, d.p(), s.p(), stats);
     if (stats) stats->persistent_fallbacks = h->n_persistent_fallbacks;
     nsx::vec_to_caller(h, d.p(), dst);
+    nsx::ilu_check(h);
   })
 }
 
@@ -603,6 +605,7 @@ int nsx_ilu_apply(nsx_handle *h, int which, double *dst, const double *src) {
     if (which == 0) nsx::ilu_solve(h, h->gA, h->schedF, h->luF.p, s.p(), d.p(), h->dim, "ilu_solve_F");
     else nsx::ilu_solve(h, h->gS, h->schedS, h->luS.p, s.p(), d.p(), 1, "ilu_solve_S");
     nsx::part_to_caller(h, which, d.p(), dst);
+    nsx::ilu_check(h);
   })
 }
 

@@ -920,6 +920,7 @@ void ilu_check(nsx_handle *h) {
   if (!herr) return;
   *err = 0;
   if (herr == 1) NSX_THROW(NSX_ERR_UNSUPPORTED, "ILU: a row has more than %d entries", ILU_MAXROW);
+  if (herr == 3) NSX_THROW(NSX_ERR_HIP, "ILU: the lane-owner triangular solve found its LDS array away from address 0 and did not run (internal: a static __shared__ object in k_ilu_solve_lanes?)");
   NSX_THROW(NSX_ERR_NUMERIC, "ILU: zero pivot");
 }
 
@@ -1046,9 +1047,16 @@ template <int NCOMP, int E, int PF>
 __global__ __launch_bounds__(64) void k_ilu_solve_lanes(const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ rows,
                                                         const int32_t *__restrict__ slab_ptr, const uint32_t *__restrict__ meta,
                                                         const double *__restrict__ val, const double *__restrict__ dinv, const double *b, double *x,
-                                                        double *__restrict__ dot_partial) {
+                                                        double *__restrict__ dot_partial, int *err_host, int force_guard) {
   extern __shared__ double xs[];  // the only LDS of this kernel: the stream's addresses are absolute (nsx_ilu_lanes.hpp)
-  if ((uint32_t)(uintptr_t)(lds_f64 *)xs != 0u) return;  // cannot happen without static LDS; a wrong result is caught by every parity test
+  // The stream's 16-bit fields are absolute LDS byte addresses: the dynamic array must start at address 0, i.e. the kernel (and
+  // every helper inlined into it) must own no static __shared__ object.  Should that ever change, x is NOT written -- so the word
+  // ilu_check() reads is raised (code 3) and the API call that ran this solve fails instead of handing back stale memory
+  // (force_guard: NSX_ILU_LDS_GUARD_TEST, tests/test_gpu_errors.py).
+  if ((uint32_t)(uintptr_t)(lds_f64 *)xs != 0u || force_guard) {
+    if (threadIdx.x == 0) __hip_atomic_store(err_host, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
   const int w = blockIdx.x;
   const unsigned lane = threadIdx.x;
   const int s0 = slab_ptr[2 * w], s1 = slab_ptr[2 * w + 1], s2 = slab_ptr[2 * w + 2];
@@ -1169,9 +1177,11 @@ template <int NCOMP>
 static void launch_lanes(nsx_handle *h, const IluSchedule &s, const double *b, double *x, double *dot_partial) {
   const size_t shm = (size_t)(s.max_wave_rows + 64) * NCOMP * sizeof(double);
   static const int pf = getenv("NSX_PF") ? atoi(getenv("NSX_PF")) : 8;
+  int *err = (int *)(h->pub_dev + N_SLOTS + 3);  // the mapped word ilu_check() reads
+  const int force_guard = getenv("NSX_ILU_LDS_GUARD_TEST") ? atoi(getenv("NSX_ILU_LDS_GUARD_TEST")) : 0;  // fault injection (tests), read per launch
 #define NSX_GO(E_, PF_)                                                                                                                        \
   hipLaunchKernelGGL((k_ilu_solve_lanes<NCOMP, E_, PF_>), dim3(s.n_waves), dim3(64), shm, h->stream, s.pk_row_ptr.p, s.pk_rows.p, s.pk_slab_ptr.p, \
-                     reinterpret_cast<const uint32_t *>(s.pk_meta.p), s.pk_val.p, s.pk_dinv.p, b, x, dot_partial)
+                     reinterpret_cast<const uint32_t *>(s.pk_meta.p), s.pk_val.p, s.pk_dinv.p, b, x, dot_partial, err, force_guard)
 #define NSX_GO_E(E_)  \
   if (pf == 4) NSX_GO(E_, 4); else NSX_GO(E_, 8)
   switch (s.stream_epl) {

@@ -62,8 +62,12 @@ struct IluStream {
 
 constexpr int ilu_meta_words(int epl) { return (epl + 2) / 2; }  // E + 1 halfwords
 constexpr int ILU_STREAM_PAD = 32;   // idle slabs behind the last wave's stream: the kernel prefetches without a bounds check
-constexpr int ILU_STREAM_ALIGN = 8;  // every sweep of every wave is a multiple of this many slabs (idle ones behind its last tick):
-                                     // the kernel runs 8 ticks as one branch-free block
+#ifndef NSX_ILU_STREAM_ALIGN
+#define NSX_ILU_STREAM_ALIGN 4
+#endif
+constexpr int ILU_STREAM_ALIGN = NSX_ILU_STREAM_ALIGN;  // every sweep of every wave is a multiple of this many slabs (idle ones behind its
+                                     // last tick): the kernel runs 8 ticks as one branch-free block and, at a sweep's END only, a block of 4
+                                     // (round 4; 8 before: the padding was 8 % of the bench stream)
 
 // g: square graph with sorted columns, structurally symmetric inside every block (FE patterns, B B^T).  bptr: [nb+1] row ranges.
 // blocks_per_wave: average number of blocks a wave serves (the wave count is ceil(nb / blocks_per_wave)).

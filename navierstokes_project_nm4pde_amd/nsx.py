@@ -24,7 +24,7 @@ API = [
     "nsx_export_block", "nsx_schur_nnz", "nsx_schur_get", "nsx_scalar_graph_nnz", "nsx_scalar_graph", "nsx_ilu_get",
     "nsx_profile_enable", "nsx_profile_reset", "nsx_profile_count", "nsx_profile_get", "nsx_persistent_state", "nsx_comm_unique_id",
     "nsx_comm_init", "nsx_comm_init_callbacks", "nsx_comm_counters", "nsx_set_mesh_distributed", "nsx_set_force_faces", "nsx_compute_forces",
-    "nsx_set_internal_layout", "nsx_layout_info", "nsx_layout_get",
+    "nsx_set_internal_layout", "nsx_layout_info", "nsx_layout_get", "nsx_gram_schmidt_cycle",
 ]
 FIRST_TOUCH, COLOUR, COLOUR_ALL = 0, 1, 2  # node order of nsx_set_internal_layout
 
@@ -69,6 +69,7 @@ def lib():
     L.nsx_set_internal_layout.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.nsx_layout_info.argtypes = [vp, C.POINTER(C.c_int)]
     L.nsx_layout_get.argtypes = [vp, _i32p, _i32p, _i32p, _i32p, _i32p]
+    L.nsx_gram_schmidt_cycle.argtypes = [vp, C.c_int, C.c_int, _f64p, C.c_double, _f64p, _f64p]
     for f in ("nsx_set_solution", "nsx_get_solution", "nsx_get_solution_ghosted", "nsx_get_rhs", "nsx_set_rhs"):
         getattr(L, f).argtypes = [vp, _f64p]
     L.nsx_assemble.argtypes = [vp, C.c_int]
@@ -347,6 +348,14 @@ class Nsx:
         dst = np.empty_like(src)
         self._ck(self.L.nsx_ilu_apply(self._h, which, _d(dst), _d(src)))
         return dst
+
+    def gram_schmidt_cycle(self, vectors, norm_guard=-1.0):
+        """nsx_gram_schmidt_cycle: (orthonormalised vectors, coefficients [m][m], |w|^2 after each sweep)"""
+        v = np.ascontiguousarray(vectors, dtype=np.float64).copy()
+        m, n = v.shape
+        coeffs, norms2 = np.zeros((m, m)), np.zeros(m)
+        self._ck(self.L.nsx_gram_schmidt_cycle(self._h, n, m, _d(v), float(norm_guard), _d(coeffs), _d(norms2)))
+        return v, coeffs, norms2
 
     # -- forces --------------------------------------------------------------------------------
     def set_force_faces(self, cells, lfaces, ftab):

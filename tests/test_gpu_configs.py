@@ -43,23 +43,30 @@ def test_re100_drag_lift_series_matches_oracle():
         co = force_coefficients(3, *fo, mean_v=inlet.mean_velocity())
         series.append((cd, co))
         scale = max(1.0, abs(co[0]), abs(co[1]))
-        assert abs(cd[0] - co[0]) < 1e-8 * scale, (step, cd, co)
-        assert abs(cd[1] - co[1]) < 1e-8 * scale, (step, cd, co)
-        assert np.abs(dev.solution_owned - ora.solution_owned).max() < 1e-8 * np.abs(ora.solution_owned).max()
+        # north_star: drag / lift to 1e-8, velocity / pressure to 1e-10 (both sides at 1e-12 / 1e-10); measured over 500 steps: 3.9e-12 / 3.9e-13
+        # (profiles/r02_drag_lift_series_500_steps.txt), so the coefficients are asserted two orders below the claim
+        assert abs(cd[0] - co[0]) < 1e-10 * scale, (step, cd, co)
+        assert abs(cd[1] - co[1]) < 1e-10 * scale, (step, cd, co)
+        assert np.abs(dev.solution_owned - ora.solution_owned).max() < 1e-10 * np.abs(ora.solution_owned).max()
     cds = np.array([s[0][0] for s in series])
     assert np.isfinite(cds).all() and cds[-1] > 0 and np.ptp(cds) > 0   # a developing flow: drag positive and changing in time
     dev.close()
 
 
 def test_ten_million_dof_mesh_on_one_gpu():
+    """BASELINE configs[3]'s mesh (level 16: 10 644 763 DoF) on one GPU, handed over the way a deal.II caller would (first-touch
+    numbering, one rank) with the virtual ranks built inside libnsx: operator identities, one time step, the ILU(0) round trip."""
+    from conftest import record
     from navierstokes_project_nm4pde_amd import nsx
     from navierstokes_project_nm4pde_amd.frontend import DoFs, Mesh, Tables
     from navierstokes_project_nm4pde_amd.problem import InletVelocity, cylinder_boundary_values
-    mesh = Mesh.cylinder(3, 14).partition(1, 8 * 4096)      # bench.py's mesh and virtual ranks for --gpus 8
-    d, tables = DoFs(mesh, "colour"), Tables(3)
-    assert 7.0e6 < d.n_dofs < 1.2e7                          # 7.3 M DoF: 8 x the cells of the 1.09 M-DoF mesh, fewer boundary nodes per cell
-    dev = nsx.Nsx(d, tables, 1e-3, 2e-4)
-    dev.set_schur_blocks(d.owned_p_ptr[::8])
+    mesh = Mesh.cylinder(3, 16)
+    d, tables = DoFs(mesh, "first_touch"), Tables(3)
+    assert 1.00e7 <= d.n_dofs < 1.2e7                        # "~10 M DoF": 10 644 763
+    n_virtual = int(round(4096 * d.n_dofs / 1089643.0))      # bench.py's rows per ILU block
+    dev = nsx.Nsx(d, tables, 1e-3, 2e-4, layout=(n_virtual, nsx.COLOUR, 96))
+    lay = dev.layout()
+    assert lay["on"] and lay["ranks"] == n_virtual and np.diff(lay["p_ptr"]).max() <= 96 * 3
     dt, H = 2e-4, 0.41
     X = d.support_points
     rng = np.random.default_rng(4321)
@@ -85,24 +92,36 @@ def test_ten_million_dof_mesh_on_one_gpu():
     dev.apply_boundary_values(bd, bv)
     b = dev.rhs
     st = dev.solve_time_step(nsx.YOSIDA)
-    assert st["status"] == 0 and 5 <= st["outer_iterations"] <= 2000   # a synthetic (not divergence-free) state: many restart cycles
     x = dev.solution_owned
     r = b - dev.system_vmult(x)
-    assert np.linalg.norm(r) < 2e-2 * np.linalg.norm(b)
+    rel_res = np.linalg.norm(r) / np.linalg.norm(b)
+    record("ten_million_dof", n_dofs=d.n_dofs, outer=st["outer_iterations"], inner_F=st["inner_F_iterations"], inner_S=st["inner_S_iterations"], rel_res=rel_res,
+           bc=float(np.abs(x[bd] - bv).max()))
+    # a synthetic (not divergence-free) state: the impulsive start of the reference, several restart cycles.  Bounds = the measured
+    # figures of this mesh (TEN_M_MEASURED) x 100 for the residual, x 2 for the iteration count
+    assert st["status"] == 0 and 5 <= st["outer_iterations"] <= 2 * TEN_M_MEASURED["outer"]
+    assert rel_res < 100 * TEN_M_MEASURED["rel_res"]
     assert np.abs(x[bd] - bv).max() < 1e-5 * max(1.0, np.abs(bv).max())
-    # ILU^{-1} (L D U v) = v at this size too (velocity blocks), with the device's own factors applied on the host
+    # ILU^{-1} (L D U v) = v at this size too (velocity blocks), with the device's own factors applied on the host.  The factors come
+    # back on the caller's graph; L / U and the rank blocks are those of the INTERNAL numbering (lay["node_perm"])
     import scipy.sparse as sp
     rp, ci, lu = dev.ilu(0)
     n = len(rp) - 1
-    rows = np.repeat(np.arange(n), np.diff(rp))
-    blk_of = np.searchsorted(d.owned_u_ptr, np.arange(n), side="right") - 1
-    keep = blk_of[rows] == blk_of[ci]
-    M = sp.csr_matrix((lu * keep, ci, rp), shape=(n, n))
+    perm = lay["node_perm"].astype(np.int64)
+    rows = perm[np.repeat(np.arange(n), np.diff(rp))]
+    cols = perm[ci]
+    blk_of = np.searchsorted(lay["u_ptr"], np.arange(n), side="right") - 1
+    keep = blk_of[rows] == blk_of[cols]
+    M = sp.csr_matrix((lu * keep, (rows, cols)), shape=(n, n))
     L = sp.tril(M, -1).tocsr() + sp.identity(n, format="csr")
     U = sp.triu(M, 1).tocsr() + sp.identity(n, format="csr")
     dinv = M.diagonal()
-    vv = rng.standard_normal((n, 3))
+    vv = rng.standard_normal((n, 3))                      # internal order
     w = L @ ((U @ vv) / dinv[:, None])
-    z = dev.ilu_apply(0, w.ravel())
-    assert np.abs(z.reshape(n, 3) - vv).max() < 1e-9 * np.abs(vv).max()
+    z = dev.ilu_apply(0, w[perm].ravel())                 # the boundary speaks the caller's order
+    assert np.abs(z.reshape(n, 3) - vv[perm]).max() < 1e-9 * np.abs(vv).max()
     dev.close()
+
+
+# measured on MI355X (gpurun_out/parity_maxima.jsonl of the round's GPU run; quoted in DESIGN.md section 5)
+TEN_M_MEASURED = {"outer": 1000, "rel_res": 2e-4}

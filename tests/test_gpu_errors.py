@@ -370,3 +370,68 @@ def test_rank_tables_with_empty_ranks_factor_and_solve_like_the_table_without_th
     for key in ("outer_iterations", "inner_F_iterations", "inner_S_iterations"):
         assert abs(a[5][key] - b[5][key]) <= max(1, 0.05 * a[5][key]), key
     assert np.abs(a[4] - b[4]).max() < 1e-3 * np.abs(a[4]).max()
+
+
+def test_lane_owner_solve_that_cannot_run_fails_the_call(monkeypatch):
+    """k_ilu_solve_lanes needs its dynamic LDS array at address 0 (the stream holds absolute LDS addresses).  If that ever breaks,
+    the kernel does not write x: the call must FAIL (mapped error word, ilu_check), not hand back stale memory.  The condition
+    cannot be produced from outside, so the kernel's guard is forced (NSX_ILU_LDS_GUARD_TEST)."""
+    from navierstokes_project_nm4pde_amd.nsx import NsxError
+    p = Problem("cylinder", 3, 2, n_sub=24, ordering="colour")
+    dev = p.device()
+    dev.set_solution(p.smooth_velocity())
+    dev.assemble(1)
+    dev.prec_initialize(0)
+    b = np.random.default_rng(2).standard_normal(p.dofs.n_u)
+    good = dev.ilu_apply(0, b)
+    assert np.isfinite(good).all()
+    monkeypatch.setenv("NSX_ILU_LDS_GUARD_TEST", "1")
+    with pytest.raises(NsxError) as e:
+        dev.ilu_apply(0, b)
+    assert "LDS" in str(e.value)
+    monkeypatch.delenv("NSX_ILU_LDS_GUARD_TEST")
+    assert (dev.ilu_apply(0, b) == good).all()   # the handle is usable again
+    dev.close()
+
+
+def test_norm_after_the_sweep_from_the_gram_matrix(prob):
+    """|w'|^2 = |w|^2 - 2 h.r + h^T G h (k_mgs_one, k_ls_solve) against the explicitly summed norm, on the sweep kernel itself
+    (nsx_gram_schmidt_cycle): (a) where the sweep leaves more than 1 % of the norm the two agree to 1e-13 relative and the
+    default takes the formula; (b) a nearly dependent vector makes the default take the explicit sum (bitwise the always-explicit
+    run), which is right to 1e-10 where the formula alone has lost most of its digits."""
+    dev = prob.device()
+    rng = np.random.default_rng(17)
+    n, m = 200000, 12
+    V = rng.standard_normal((m, n))
+    V[5] = 0.3 * V[5] + V[:5].sum(axis=0)                  # a good share of it lies in the span of the vectors before it, > 1 % is left
+    V[m - 1] = V[:m - 1].sum(axis=0) + 1e-7 * V[m - 1]     # nearly dependent: the sweep removes all but 1e-14 of |w|^2
+    Qf, Hf, nf = dev.gram_schmidt_cycle(V, norm_guard=0.0)      # always the formula
+    Qx, Hx, nx = dev.gram_schmidt_cycle(V, norm_guard=1e300)    # always the explicit sum
+    Qd, Hd, nd = dev.gram_schmidt_cycle(V)                      # the library's threshold (1e-2)
+    # reference: modified Gram-Schmidt in numpy
+    Q = np.zeros_like(V)
+    Q[0] = V[0] / np.linalg.norm(V[0])
+    true_n2 = np.zeros(m)
+    true_n2[0] = V[0] @ V[0]
+    for k in range(1, m):
+        w = V[k].copy()
+        for i in range(k):
+            w -= (w @ Q[i]) * Q[i]
+        true_n2[k] = w @ w
+        Q[k] = w / np.sqrt(true_n2[k])
+    before = np.array([V[k] @ V[k] for k in range(m)])
+    for k in range(1, m - 1):
+        assert true_n2[k] > 0.01 * before[k]
+        assert abs(nf[k] - nx[k]) <= 1e-13 * nx[k], (k, nf[k], nx[k])      # (a) formula == explicit sum
+        assert nd[k] == nf[k]                                             # ... and it is the formula the default used
+        assert abs(nx[k] - true_n2[k]) <= 1e-12 * true_n2[k]
+    k = m - 1
+    assert true_n2[k] < 1e-10 * before[k]
+    # (b) the default refused the formula: it agrees with the always-explicit run to the rounding the EARLIER sweeps differ by
+    # (those normalised their vectors with the formula's norm in one run and the explicit one in the other: 1e-13 apart)
+    # (the vector itself is what is left of a cancellation by seven digits: the two runs' 1e-13 differences in the basis show up at 1e-7 in it)
+    assert abs(nd[k] - nx[k]) <= 1e-9 * nx[k] and np.abs(Qd[k] - Qx[k]).max() <= 1e-5 * np.abs(Qx[k]).max()
+    assert abs(nx[k] - true_n2[k]) <= 1e-8 * true_n2[k]
+    assert abs(nf[k] - true_n2[k]) > 1e-6 * true_n2[k]                     # the formula alone: a difference of numbers 1e14 times larger
+    assert np.abs(Hd - Hx).max() <= 1e-12 * np.abs(Hx).max()
+    dev.close()

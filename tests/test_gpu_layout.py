@@ -230,7 +230,9 @@ def test_time_steps_tight_tolerance(trio, prec):
             # of iterations at 1e-10 and its count moves by a few per cent with the rounding (measured 6699 against 7100)
             assert abs(sL[key] - so[key]) <= max(2, (0.10 if key == "inner_S_iterations" else 0.05) * so[key]), key
         xo = t.pd.to_old(t.ora.solution_owned)
-        assert np.abs(xL - xo).max() / np.abs(xo).max() < 1e-8
+        nu_ = p.dofs.n_u   # north_star: velocity and pressure within 1e-10 relative at tightened tolerances (measured maxima: DESIGN.md section 5)
+        assert np.abs(xL[:nu_] - xo[:nu_]).max() / np.abs(xo[:nu_]).max() < 1e-10
+        assert np.abs(xL[nu_:] - xo[nu_:]).max() / np.abs(xo[nu_:]).max() < 1e-10
 
 
 def test_reference_tolerances(trio):

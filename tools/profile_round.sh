@@ -5,7 +5,7 @@
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
-TAG=${1:-r03}
+TAG=${1:-r04}
 python3 $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || exit 1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu --profile-steps 0 > $OUT/${TAG}_stats.json 2> $OUT/${TAG}_stats.err || exit 2
