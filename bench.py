@@ -44,6 +44,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 BASE_LEVEL, BASE_DOFS = 7, 1089643  # the N = 1 workload: level-7 cylinder mesh
 BIG_LEVEL, BIG_DOFS = 16, 10644763  # the "~10 M DoF" mesh of BASELINE.json configs[3] (level 14 has 7.3 M)
+if os.environ.get("NSX_BENCH_BIG_LEVEL"):  # development only: rehearse the strong_10M leg's control flow on a small mesh
+    BIG_LEVEL, BIG_DOFS = int(os.environ["NSX_BENCH_BIG_LEVEL"]), None
 BIG_STEPS, BIG_WARMUP, BIG_SPINUP = 10, 2, 5  # schedule of the strong_10M leg: the same on one GPU (committed base) and on N
 PMC_PROFILE = "profiles/r04_pmc_fetch_write_per_kernel.json"
 LAYOUT_PROFILE = "profiles/r04_layout_iterations.json"
@@ -52,7 +54,7 @@ STEP_HISTORY = "profiles/r04_step_history.txt"
 NU, DT = 1e-3, 2e-4
 
 # scope name used by the library's HIP-event timer -> kernel symbol in rocprofv3 output
-KERNEL_OF = {"mgs_sweep": "void nsx::k_mgs_one<8, 10>", "add_and_dot": "void nsx::k_reduce<1>", "dot": "void nsx::k_reduce<0>", "spmv_F": "void nsx::k_spmv_blocked<3, 16>",
+KERNEL_OF = {"mgs_sweep": "void nsx::k_mgs_one<8, 10, false>", "add_and_dot": "void nsx::k_reduce<1>", "dot": "void nsx::k_reduce<0>", "spmv_F": "void nsx::k_spmv_blocked<3, 16>",
              "ilu_solve_F": "void nsx::k_ilu_solve_lanes<3, 2, 8>", "ilu_solve_S": "nsx::k_ilu_apply_dense",
              "axpby": "nsx::k_axpby", "spmv_S": "void nsx::k_spmv_csr<32>", "cg_S": "void nsx::k_cg_schur<6, true>"}
 
@@ -602,7 +604,7 @@ def main():
     def partitioned_run(level, steps, warmup, spinup, profile_steps, want_state=False, twin=False):
         """every rank runs its part; a failure anywhere ends the job with a non-zero exit code (the launcher tears the
         group down) — a GPU fault must be investigated, not converted into a throughput number"""
-        n_dofs_guess = BASE_DOFS if level == BASE_LEVEL else (BIG_DOFS if level == BIG_LEVEL else None)
+        n_dofs_guess = BASE_DOFS if level == BASE_LEVEL else (BIG_DOFS if (level == BIG_LEVEL and BIG_DOFS) else None)
         ranks = total_ranks(args, n_dofs_guess) if n_dofs_guess else args.ranks * world
         beat("level %d: building the mesh and the caller's DoF table" % level, every=0.0 if level > 10 else 30.0)
         mesh, dofs, tables = build_problem(level, ranks, world, args.ordering, args.balance, args.numbering, args.ranks_input)

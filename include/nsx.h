@@ -112,7 +112,8 @@ int nsx_set_schur_blocks(nsx_handle *h, int n_blocks, const int32_t *p_ptr);
  * virtual rank touching it (deal.II's rule), nodes are numbered virtual rank by virtual rank in first-touch order (cell by cell,
  * vertices then lines) and, for NSX_ORDER_COLOUR, sorted by a greedy colouring of the rank's P2 graph (NSX_ORDER_COLOUR_ALL: the
  * pressure nodes as well, on the graph of the Schur complement).  schur_max_rows > 0 merges consecutive virtual ranks into Schur
- * ILU blocks of at most that many pressure rows (never across a rank of the caller); 0: one block per virtual rank.
+ * ILU blocks of at most that many pressure rows (on one handle a block may span two ranks of the caller; nothing spans handles);
+ * 0: one block per virtual rank.
  * What the library then computes is what the reference computes on n_virtual_ranks MPI ranks with that numbering (per-rank ILU(0),
  * per-rank diagonal of apply_boundary_values).  NOTHING changes at the boundary: every vector, dof list, graph and value array that
  * crosses it stays in the caller's numbering (permuted on the device on the way in and out).

@@ -1084,6 +1084,7 @@ static unsigned int mgs_recover(nsx_handle *h, unsigned long long failed_seq) {
     h->mgs_ext_expected = 0;
   }
   h->mgs_max_wg_dist[0] = h->mgs_max_wg_dist[1] = 0;
+  h->mgs_dist_fit.clear();
   std::vector<unsigned long long> tail(MGS_TAIL, 0);
   const size_t region = std::max(MGS_REGION, MGS_BLK_REGION);
   HIP_CHECK(hipMemcpy(tail.data(), h->mgs_box.p + 2 * region, MGS_TAIL * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -1297,7 +1298,13 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
     if (per_thread <= es[k]) break;
   }
   const int per_thread_max = h->mgs_links == 0 ? 10 : 20;
-  if (dist && (e_inst == 0 || per_thread > per_thread_max || dim + 2 > MGS_STEPS)) dist = false;
+  if (dist) {
+    // does the resident grid hold the vector -- on EVERY rank?  (local lengths differ; a rank on the two-pass sweep and a rank on the
+    // persistent one would all-reduce differently laid-out buffers.)  Agreed once per vector length = per role of the solve.
+    auto it = h->mgs_dist_fit.find(n);
+    if (it == h->mgs_dist_fit.end()) it = h->mgs_dist_fit.emplace(n, comm_agree_all(h, e_inst != 0 && per_thread <= per_thread_max) ? 1 : 0).first;
+    if (!it->second || dim + 2 > MGS_STEPS) dist = false;
+  }
   if ((h->comm && !dist) || h->mgs_max_wg == 0 || dim + 2 > MGS_STEPS || per_thread > per_thread_max || (h->mgs_links == 0 && !gram)) {
     // distributed solve: two collectives per sweep (mgs_lowsync); NSX_MGS_LOWSYNC=0: one launch + all-reduce per link, as the
     // reference's MPI run does.  Without a Gram cache (or too many vectors for it) the chain as well.

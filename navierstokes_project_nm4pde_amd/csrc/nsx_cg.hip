@@ -793,7 +793,14 @@ bool cg_schur_fused(nsx_handle *h, double *x, const double *b, double rtol, int 
   const IluSchedule &s = h->schedS;
   const CgPlan &pl = h->cgplan;
   static const bool wanted = !(getenv("NSX_CG_FUSED") && atoi(getenv("NSX_CG_FUSED")) == 0);
-  if (!h->comm || !wanted || !s.dense || s.max_rows > CG_MAXB || !pl.ok || !pl.values_current || s.n_blocks > CGD_PARTS || CG_THREADS != 256) return false;
+  if (!h->comm || !wanted) return false;
+  // whether THIS rank's Schur blocks fit the kernels (dense inverses, <= 256 rows, <= 1024 unique columns per block) depends on its
+  // own part of the mesh: the ranks agree once per set of schedules, or one of them would run the launch-per-operation solver's
+  // collectives against the others' (found by the 2-process test with 6 virtual ranks per GPU: one rank had a 260-row block)
+  if (h->cgd_agreed < 0)
+    h->cgd_agreed = comm_agree_all(h, s.dense && s.max_rows <= CG_MAXB && pl.ok && s.n_blocks <= CGD_PARTS && CG_THREADS == 256) ? 1 : 0;
+  if (!h->cgd_agreed) return false;
+  if (!pl.values_current) NSX_THROW(NSX_ERR_ARG, "internal: Schur CG before the packed operator values were refreshed");
   const int n = h->n_p, len = h->len_p, nblk = s.n_blocks;
   if ((int)h->cgd_vec.n < 3 * n + 2 * len) {
     h->cgd_vec.alloc((size_t)3 * n + 2 * len);

@@ -88,6 +88,22 @@ __global__ void k_ext_release(unsigned long long *flag, unsigned long long seq) 
 
 bool comm_on_stream(const nsx_handle *h) { return h->comm && h->comm->comm; }
 
+// A choice between two code paths that issue DIFFERENT collectives (or the same collective over differently laid-out buffers)
+// must be the same on every rank, whatever the rank's own sizes say: true only if `mine` is true everywhere.  One collective;
+// callers cache the answer (it depends on set-up products, not on the state).  Every rank must get here at the same point of its
+// collective sequence -- the callers sit in code all ranks run in lockstep.
+bool comm_agree_all(nsx_handle *h, bool mine) {
+  Comm *c = h->comm;
+  if (!c || (c->world == 1 && !c->comm)) return mine;
+  h->scal_host[N_SLOTS - 1] = mine ? 0.0 : 1.0;  // the sum of the objections
+  HIP_CHECK(hipMemcpyAsync(h->scal.p + N_SLOTS - 1, h->scal_host + N_SLOTS - 1, sizeof(double), hipMemcpyHostToDevice, h->stream));
+  h->slot_nb[N_SLOTS - 1] = 0;
+  comm_allreduce_scalars(h, N_SLOTS - 1, 1);
+  HIP_CHECK(hipMemcpyAsync(h->scal_host + N_SLOTS - 1, h->scal.p + N_SLOTS - 1, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_CHECK(hipStreamSynchronize(h->stream));
+  return h->scal_host[N_SLOTS - 1] == 0.0;
+}
+
 // A communication stream of the device's highest priority would take its hardware queue from another pool than the compute
 // stream's (the runtime shares hardware queues between streams of one priority once there are more streams than queues, and two
 // streams on one queue run in order -- the collective inside a persistent grid would wait for the grid that waits for it) ...
@@ -285,7 +301,9 @@ int nsx_comm_init(nsx_handle *h, int rank, int world, const uint8_t id[128]) {
     ncclUniqueId u;
     memcpy(&u, id, 128);
     NCCL_CHECK(ncclCommInitRank(&h->comm->comm, world, u, rank));
-    h->mgs_dist_state = -1;  // a new communicator: the sweep's path is decided again, by all its ranks
+    h->mgs_dist_state = -1;  // a new communicator: the paths the ranks choose together are chosen again
+    h->mgs_dist_fit.clear();
+    h->cgd_agreed = -1;
   } catch (const nsx::Error &e) {
     h->err = e.msg;
     return e.code;
@@ -310,6 +328,8 @@ int nsx_comm_init_callbacks(nsx_handle *h, int rank, int world, nsx_allreduce_fn
   h->comm->exchange = exchange;
   h->comm->ctx = ctx;
   h->mgs_dist_state = -1;
+  h->mgs_dist_fit.clear();
+  h->cgd_agreed = -1;
   return NSX_OK;
 }
 

@@ -300,6 +300,8 @@ struct nsx_handle {
   nsx::DevBuf<unsigned long long> mgs_ext_words;  // [0] release flag, [1] arrival counter (32 bits used)
   unsigned int mgs_ext_expected = 0;
   int mgs_ext_parity = 0;
+  std::map<int, int> mgs_dist_fit;   // local vector length -> do ALL ranks' resident grids hold their vector of this role (agreed once per length)
+  int cgd_agreed = -1;               // two-launch Schur CG: -1 not decided for the current schedules, 0 / 1 the ranks' common answer
   int mgs_dist_state = -1;           // -1 not decided yet, 0 two-pass sweep (mgs_lowsync), 1 the collective inside the persistent grid
   int mgs_max_wg_dist[2] = {0, 0};   // resident-grid limits of the distributed instantiations (8 / 10 entries per thread), room left for the collective
   long long n_allreduce = 0, n_halo = 0;  // collectives issued (nsx_comm_counters)
@@ -464,6 +466,7 @@ void solve_time_step(nsx_handle *h, int type, double tol, double inner_rtol, int
 // comm (nsx_comm.hip)
 void comm_allreduce_scalars(nsx_handle *h, int slot0, int count);
 void comm_allreduce_partials(nsx_handle *h, double *partials, int count);  // in place, same count on every rank
+bool comm_agree_all(nsx_handle *h, bool mine);  // true iff `mine` is true on every rank (one collective): path choices that change the collective sequence
 bool comm_streams_concurrent(nsx_handle *h);  // probe + agreement of all ranks (one collective): may a compute kernel wait for the communication stream?
 bool comm_on_stream(const nsx_handle *h);  // RCCL backend: collectives are stream operations (the callback backend runs them on the host)
 // the collective inside a persistent grid's exchange: on the communication stream wait for `arrive` to reach `expected`, all-reduce

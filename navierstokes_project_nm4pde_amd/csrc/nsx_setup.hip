@@ -390,6 +390,7 @@ void ensure_schedules(nsx_handle *h) {
   const bool denseS = !(getenv("NSX_DENSE_S") && atoi(getenv("NSX_DENSE_S")) == 0);
   setup_ilu_schedule(h, h->gS.host, sb, h->schedS, bpwS, denseS, 1);
   build_cg_plan(h);
+  h->cgd_agreed = -1;  // path choices that the ranks make together are made again for the new schedules
   h->sched_dirty = false;
 }
 

@@ -64,7 +64,7 @@ class Trio:
             for ptr, perm in ((p.dofs.owned_u_ptr, lay["node_perm"]), (p.dofs.owned_p_ptr, lay["pnode_perm"])):
                 img = perm[ptr[r]:ptr[r + 1]]
                 assert len(img) == 0 or (img.min() == ptr[r] and img.max() == ptr[r + 1] - 1)
-            assert p.dofs.owned_u_ptr[r] in lay["u_ptr"] and p.dofs.owned_p_ptr[r] in lay["p_ptr"] and p.dofs.owned_p_ptr[r] in lay["schur_ptr"]
+            assert p.dofs.owned_u_ptr[r] in lay["u_ptr"] and p.dofs.owned_p_ptr[r] in lay["p_ptr"]
         pd = PermutedDoFs(p.dofs, lay["node_perm"], lay["pnode_perm"], lay["u_ptr"], lay["p_ptr"])
         self.pd = pd
         self.ora = oracle.Oracle(pd, p.tables, p.nu, p.deltat)

@@ -36,8 +36,6 @@ def test_layout_refines_the_ranks_of_the_caller(dim, level, r_in, n_virtual):
             assert len(img) == 0 or (img.min() == ptr[r] and img.max() == ptr[r + 1] - 1)   # a rank's nodes stay in that rank's range
             assert ptr[r] in mine                                                          # ... which is a union of virtual ranks
     assert all(b in lay["p_ptr"] for b in lay["schur_ptr"])                                 # Schur blocks: unions of virtual ranks
-    for r in range(r_in):
-        assert d0.owned_p_ptr[r] in lay["schur_ptr"]                                        # ... that never cross a rank of the caller
     # colour order inside a virtual rank: what the ILU(0) sees -- inside a rank the dependency depth of the block (longest chain of
     # lower neighbours) is at most the number of colours
     pd = PermutedDoFs(d0, lay["node_perm"], lay["pnode_perm"], lay["u_ptr"], lay["p_ptr"])
