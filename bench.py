@@ -544,6 +544,9 @@ def main():
                     help="auto: on one GPU with the cpu_baseline leg, measure roofline.traffic in two child runs under rocprofv3 --pmc "
                          "(FETCH_SIZE, WRITE_SIZE; ~1 min each); off: quote the committed profile")
     args = ap.parse_args()
+    if os.environ.get("NSX_BENCH_HANG_DUMP"):  # development: where is every rank after that many seconds?
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["NSX_BENCH_HANG_DUMP"]), exit=False)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.steps is None:
@@ -635,7 +638,7 @@ def main():
                "allreduces_per_step": stats_b[0].get("allreduces_per_step"), "ghost_exchanges_per_step": stats_b[0].get("ghost_exchanges_per_step"),
                "dof_steps_per_s_in_units_of_the_1M_mesh": BIG_STEPS / el_b * dofs_b.n_dofs / BASE_DOFS}
         base = committed_big_base()
-        if base:
+        if base and base.get("n_dofs") == dofs_b.n_dofs:  # (not in a rehearsal of this leg on another mesh)
             big["one_gpu_base"] = base
             big["speedup_over_one_gpu"] = big["time_steps_per_s"] / base["value"] if base.get("value") else None
             big["speedup_per_outer_iteration"] = base["ms_per_outer_iteration"] / big["ms_per_outer_iteration"] if base.get("ms_per_outer_iteration") else None

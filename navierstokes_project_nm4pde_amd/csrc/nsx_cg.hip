@@ -642,6 +642,14 @@ __device__ __forceinline__ double cgd_sum(const double *__restrict__ p, double *
   for (int k = 0; k < CGD_PARTS / 256; ++k) a += p[threadIdx.x + 256 * k];
   return gx_block_sum(a, sh);
 }
+// The collectives add the ranks' partial-sum arrays element by element IN PLACE: entries beyond this rank's own block count hold the
+// other ranks' sums afterwards, and would be added again the next time the array goes out.  The last workgroup clears them (n_arrays
+// consecutive arrays of CGD_PARTS entries) in every launch that fills the array.
+__device__ __forceinline__ void cgd_clear_tail(double *arrays, int n_arrays) {
+  if (blockIdx.x != gridDim.x - 1) return;
+  for (int a = 0; a < n_arrays; ++a)
+    for (int q = (int)gridDim.x + (int)threadIdx.x; q < CGD_PARTS; q += CG_THREADS) arrays[(size_t)a * CGD_PARTS + q] = 0.0;
+}
 __device__ __forceinline__ void cgd_dense_apply(const double *__restrict__ Pb, int nb, const double *gs, double *hs, int tid) {
   const int grp = tid >> 4, lane = tid & 15;
   for (int q = grp; q < nb; q += CG_NG) {
@@ -696,6 +704,7 @@ __global__ __launch_bounds__(CG_THREADS) void k_cgd_init(const int32_t *__restri
     parts[CGD_P0 + CGD_PARTS + wg] = gh;
     parts[CGD_BB + wg] = bb;
   }
+  cgd_clear_tail(parts + CGD_P0, 3);
 }
 
 // the direction of iteration `it` for the nodes a neighbour needs (the communication stream's pack kernel): the owner's expression
@@ -756,6 +765,7 @@ __global__ __launch_bounds__(CG_THREADS) void k_cgd_A(const int32_t *__restrict_
   if (own) Hv[r0 + tid] = hvs[tid];
   const double dh = gx_block_sum(own ? ds[tid] * hvs[tid] : 0.0, sh[3]);
   if (tid == 0) part_dh[wg] = dh;
+  cgd_clear_tail(part_dh, 1);
 }
 
 __global__ __launch_bounds__(CG_THREADS) void k_cgd_B(const int32_t *__restrict__ bptr, const int64_t *__restrict__ dn_off, const double *__restrict__ P, int it,
@@ -787,6 +797,7 @@ __global__ __launch_bounds__(CG_THREADS) void k_cgd_B(const int32_t *__restrict_
     mine[wg] = gg;
     mine[CGD_PARTS + wg] = ghn;
   }
+  cgd_clear_tail(mine, 2);
 }
 
 bool cg_schur_fused(nsx_handle *h, double *x, const double *b, double rtol, int maxiter, int *steps, double *last, int *status) {
@@ -822,8 +833,10 @@ bool cg_schur_fused(nsx_handle *h, double *x, const double *b, double rtol, int 
   comm_allreduce_partials(h, parts + CGD_P0, 3 * CGD_PARTS);
   int it = 0, conv = 0;
   double tol = 0.0, res = 0.0;
+  static const bool trace = getenv("NSX_TRACE") != nullptr;
   for (;;) {
     const int nx = it + 1;
+    if (trace && (it < 3 || it % 200 == 0)) fprintf(stderr, "[nsx trace] rank %d: Schur CG iteration %d, residual %.3e, tolerance %.3e\n", h->rank, it, res, tol);
     double *Dp = D[(nx + 1) & 1], *Dc = D[nx & 1];
     // ghost entries of the next direction: the owners evaluate the same expression for the nodes their neighbours need
     if (h->dist && !h->haloP.nbr.empty()) {

@@ -149,6 +149,8 @@ static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b,
     double rho_before = 0.0;  // residual estimate one iteration earlier (0: none yet in this cycle)
     for (int inner = 0; inner < N_TMP - 2 && state == 0; ++inner) {
       ++accumulated;
+      static const bool trace = getenv("NSX_TRACE") != nullptr;
+      if (trace && h->gmres_depth == 1) fprintf(stderr, "[nsx trace] rank %d: outer iteration %d, residual %.3e\n", h->rank, accumulated, rho);
       double *vv = vec(inner + 1);
       // (already enqueued behind the previous iteration's Gram-Schmidt sweep when `ahead`)
       auto apply_AP = [&](double *dst, const double *src) {  // dst = P (A src)
@@ -496,9 +498,12 @@ void solve_time_step(nsx_handle *h, int type, double tol, double inner_rtol, int
   double t0 = now_s();
   h->defer_red = false;  // a solve that unwound in the middle of a batched reduction must not leave the handle deferring
   h->pending_red.clear();
+  static const bool trace = getenv("NSX_TRACE") != nullptr;
+  if (trace) fprintf(stderr, "[nsx trace] rank %d: solve_time_step: preconditioner set-up\n", h->rank);
   prec_initialize(h, type);  // NS3D.cpp:568-569
   HIP_CHECK(hipStreamSynchronize(h->stream));
   prec_confirm(h);
+  if (trace) fprintf(stderr, "[nsx trace] rank %d: solve_time_step: outer solve\n", h->rank);
   st->t_prec = now_s() - t0;
   t0 = now_s();
   Op A = [h](double *d, const double *s) { spmv_saddle(h, s, d); };

@@ -28,7 +28,8 @@ def main():
     dofs, tables = DoFs(mesh, ordering), Tables(dim)
     dt = 2e-4 if dim == 3 else 1e-2
     dev = nsx.Nsx(dofs, tables, 1e-3, dt, device=0, rank=rank, world=world, comm="callbacks",
-                  layout=(layout_ranks, nsx.COLOUR, 24) if layout_ranks else None)
+                  # (another block count on every rank: the partial-sum arrays of the two-launch Schur CG must not carry one rank's tail into the other's sums)
+                  layout=(layout_ranks + 3 * rank, nsx.COLOUR, 24) if layout_ranks else None)
     if layout_ranks:
         info = dev.layout_info()
         assert info["on"] and info["ranks"] >= 2
