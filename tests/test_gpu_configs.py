@@ -101,7 +101,7 @@ def test_ten_million_dof_mesh_on_one_gpu():
     # figures of this mesh (TEN_M_MEASURED) x 100 for the residual, x 2 for the iteration count
     assert st["status"] == 0 and 5 <= st["outer_iterations"] <= 2 * TEN_M_MEASURED["outer"]
     assert rel_res < 100 * TEN_M_MEASURED["rel_res"]
-    assert np.abs(x[bd] - bv).max() < 1e-5 * max(1.0, np.abs(bv).max())
+    assert np.abs(x[bd] - bv).max() < 1e-12 * max(1.0, np.abs(bv).max())
     # ILU^{-1} (L D U v) = v at this size too (velocity blocks), with the device's own factors applied on the host.  The factors come
     # back on the caller's graph; L / U and the rank blocks are those of the INTERNAL numbering (lay["node_perm"])
     import scipy.sparse as sp
@@ -124,4 +124,4 @@ def test_ten_million_dof_mesh_on_one_gpu():
 
 
 # measured on MI355X (gpurun_out/parity_maxima.jsonl of the round's GPU run; quoted in DESIGN.md section 5)
-TEN_M_MEASURED = {"outer": 1000, "rel_res": 2e-4}
+TEN_M_MEASURED = {"outer": 411, "rel_res": 4.1e-10}   # 411 outer / 22 574 inner-F / 9 852 inner-S iterations, Dirichlet values reproduced to 1.8e-15; 68 s
