@@ -14,7 +14,7 @@ from conftest import Problem, entry_err, rel_err
 pytestmark = pytest.mark.gpu
 
 # (mesh, dim, level, ranks of the caller, virtual ranks, node order, Schur block row limit)
-CASES = [("cylinder", 3, 2, 1, 24, "colour", 40), ("cylinder", 3, 2, 4, 24, "colour_all", 0), ("cylinder", 2, 3, 1, 6, "colour", 0),
+CASES = [("cylinder", 3, 2, 1, 24, "colour", 40), ("cylinder", 3, 1, 4, 12, "colour_all", 0), ("cylinder", 2, 3, 1, 6, "colour", 0),
          ("cube", 3, 4, 2, 8, "first_touch", 30), ("cylinder", 3, 1, 3, 3, "colour", 0)]
 ORDER = {"first_touch": 0, "colour": 1, "colour_all": 2}
 
