@@ -999,9 +999,11 @@ __global__ __launch_bounds__(256) void k_mgs_one(int n, int split, int gap, doub
   MGS_STAMP();  // stores issued
 }
 
+// entries per thread x basis vectors kept in registers: 8 x 10, 10 x 8, 12 x 6 (round 4: 1.28 M velocity dofs per GPU -- the 10.6 M-DoF mesh
+// on 8 GPUs -- need 11.1 entries per thread of the 448-workgroup grid a distributed sweep may use; one GPU: vectors up to 1.57 M entries)
 static const void *mgs_one_fn(int e, bool dist = false) {
-  if (dist) return e <= 8 ? (const void *)k_mgs_one<8, 10, true> : (const void *)k_mgs_one<10, 8, true>;
-  return e <= 8 ? (const void *)k_mgs_one<8, 10, false> : (const void *)k_mgs_one<10, 8, false>;
+  if (dist) return e <= 8 ? (const void *)k_mgs_one<8, 10, true> : e <= 10 ? (const void *)k_mgs_one<10, 8, true> : (const void *)k_mgs_one<12, 6, true>;
+  return e <= 8 ? (const void *)k_mgs_one<8, 10, false> : e <= 10 ? (const void *)k_mgs_one<10, 8, false> : (const void *)k_mgs_one<12, 6, false>;
 }
 
 template <int M>
@@ -1034,7 +1036,7 @@ static void mgs_setup(nsx_handle *h) {
   h->mgs_box.alloc(2 * region + MGS_TAIL);
   HIP_CHECK(hipMemsetAsync(h->mgs_box.p, 0xff, 2 * region * sizeof(unsigned long long), h->stream));
   HIP_CHECK(hipMemsetAsync(h->mgs_box.p + 2 * region, 0, MGS_TAIL * sizeof(unsigned long long), h->stream));
-  const int es[3] = {8, 10, 20};
+  const int es[3] = {8, 10, h->mgs_links == 0 ? 12 : 20};
   for (int k = 0; k < 3; ++k) {
     int per_cu = 0;
     HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mgs_fn(h->mgs_links, es[k]), 256, 0));
@@ -1045,9 +1047,10 @@ static void mgs_setup(nsx_handle *h) {
   h->mgs_max_wg = h->mgs_max_wg_e[1];
   // distributed instantiations: the collective's own kernels (RCCL's all-reduce, the two one-thread kernels around it) must find a
   // place on the device WHILE the grid is resident and waiting for them: an eighth of the slots (at least 32) stays free
-  for (int k = 0; k < 2; ++k) {
+  const int es_one[3] = {8, 10, 12};
+  for (int k = 0; k < 3; ++k) {
     int per_cu = 0;
-    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mgs_one_fn(es[k], true), 256, 0));
+    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mgs_one_fn(es_one[k], true), 256, 0));
     const int slots = per_cu * cus;
     h->mgs_max_wg_dist[k] = std::max(0, std::min(MGS_MAX_WG, slots - std::max(32, slots / 8)));
     if (getenv("NSX_MGS_MAXWG")) h->mgs_max_wg_dist[k] = std::max(1, std::min(h->mgs_max_wg_dist[k], atoi(getenv("NSX_MGS_MAXWG"))));
@@ -1083,7 +1086,7 @@ static unsigned int mgs_recover(nsx_handle *h, unsigned long long failed_seq) {
     h->mgs_ext_words.zero(h->stream);
     h->mgs_ext_expected = 0;
   }
-  h->mgs_max_wg_dist[0] = h->mgs_max_wg_dist[1] = 0;
+  h->mgs_max_wg_dist[0] = h->mgs_max_wg_dist[1] = h->mgs_max_wg_dist[2] = 0;
   h->mgs_dist_fit.clear();
   std::vector<unsigned long long> tail(MGS_TAIL, 0);
   const size_t region = std::max(MGS_REGION, MGS_BLK_REGION);
@@ -1287,9 +1290,9 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
   dist = dist && h->mgs_links == 0 && 2 * dim + 1 < MGS_EXT_FAIL;
   // entries per thread: the smallest instantiation (8, 10, 20) whose resident grid covers the vector
   int nwg = 1, per_thread = 1 << 30, e_inst = 0;
-  const int n_inst = h->mgs_links == 0 ? 2 : 3;  // the one-exchange sweep keeps a block of basis vectors in registers: 8 or 10 entries per thread
+  const int n_inst = 3;  // the one-exchange sweep keeps a block of basis vectors in registers: 8, 10 or 12 entries per thread
   for (int k = 0; k < n_inst && h->mgs_max_wg; ++k) {
-    static const int es[3] = {8, 10, 20};
+    const int es[3] = {8, 10, h->mgs_links == 0 ? 12 : 20};
     const int cap = dist ? h->mgs_max_wg_dist[k] : h->mgs_max_wg_e[k];
     if (cap <= 0) continue;
     nwg = std::max(1, std::min(cap, cdiv(n, 256 * 4)));
@@ -1297,7 +1300,7 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
     e_inst = es[k];
     if (per_thread <= es[k]) break;
   }
-  const int per_thread_max = h->mgs_links == 0 ? 10 : 20;
+  const int per_thread_max = h->mgs_links == 0 ? 12 : 20;
   if (dist) {
     // does the resident grid hold the vector -- on EVERY rank?  (local lengths differ; a rank on the two-pass sweep and a rank on the
     // persistent one would all-reduce differently laid-out buffers.)  Agreed once per vector length = per role of the solve.

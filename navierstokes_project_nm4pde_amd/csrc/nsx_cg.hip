@@ -617,7 +617,7 @@ bool cg_schur_persistent(nsx_handle *h, double *x, const double *b, double rtol,
 }
 
 
-// ---- the same solve in a DISTRIBUTED run: TWO launches per iteration ----------------------------------------------------------------
+// ---- the same solve in TWO launches per iteration: distributed runs, and one GPU with more Schur blocks than resident workgroups ----
 // With a communicator the solve cannot stay in one launch: the neighbours' d comes through a ghost exchange and the two sums of an
 // iteration through collectives the host enqueues.  The launch-per-operation solver (nsx_solve.hip: cg) pays five to six kernels
 // per iteration; here the persistent kernel's two phases are cut at its two exchanges and nothing else:
@@ -804,7 +804,7 @@ bool cg_schur_fused(nsx_handle *h, double *x, const double *b, double rtol, int 
   const IluSchedule &s = h->schedS;
   const CgPlan &pl = h->cgplan;
   static const bool wanted = !(getenv("NSX_CG_FUSED") && atoi(getenv("NSX_CG_FUSED")) == 0);
-  if (!h->comm || !wanted) return false;
+  if (!wanted) return false;  // (one GPU: reached when the persistent kernel cannot run -- more Schur blocks than resident workgroups, i.e. beyond ~1.16 M DoF)
   // whether THIS rank's Schur blocks fit the kernels (dense inverses, <= 256 rows, <= 1024 unique columns per block) depends on its
   // own part of the mesh: the ranks agree once per set of schedules, or one of them would run the launch-per-operation solver's
   // collectives against the others' (found by the 2-process test with 6 virtual ranks per GPU: one rank had a 260-row block)

@@ -286,7 +286,7 @@ struct nsx_handle {
   bool sched_dirty = true;  // the ILU schedules do not match the current rank tables yet
   int mgs_used_wg[2] = {0, 0}, mgs_used_steps[2] = {0, 0};  // what the last launch on each region filled
   int mgs_parity = 0, mgs_max_wg = 0;  // mgs_max_wg = 0: the launch-per-link chain is used
-  int mgs_max_wg_e[3] = {0, 0, 0};     // resident-grid limit of the 8 / 10 / 20 entries-per-thread instantiations
+  int mgs_max_wg_e[3] = {0, 0, 0};     // resident-grid limit of the 8 / 10 / 12 (link-by-link variants: 20) entries-per-thread instantiations
   int mgs_links = 2;                   // links of the add_and_dot chain per grid-wide exchange (NSX_MGS_LINKS; 1 = k_mgs)
   bool mgs_disabled = false;
   double mgs_guard_override = -1.0;    // >= 0: threshold of the Gram formula for |w'|^2 for the duration of nsx_gram_schmidt_cycle
@@ -303,7 +303,7 @@ struct nsx_handle {
   std::map<int, int> mgs_dist_fit;   // local vector length -> do ALL ranks' resident grids hold their vector of this role (agreed once per length)
   int cgd_agreed = -1;               // two-launch Schur CG: -1 not decided for the current schedules, 0 / 1 the ranks' common answer
   int mgs_dist_state = -1;           // -1 not decided yet, 0 two-pass sweep (mgs_lowsync), 1 the collective inside the persistent grid
-  int mgs_max_wg_dist[2] = {0, 0};   // resident-grid limits of the distributed instantiations (8 / 10 entries per thread), room left for the collective
+  int mgs_max_wg_dist[3] = {0, 0, 0};  // resident-grid limits of the distributed instantiations (8 / 10 / 12 entries per thread), room left for the collective
   long long n_allreduce = 0, n_halo = 0;  // collectives issued (nsx_comm_counters)
   bool mgs_redo_ahead = false;         // a sweep fell back to the chain after work depending on its w had been enqueued
   // persistent Schur-complement CG (nsx_cg.hip: k_cg_schur): mailbox regions, work vectors (d double-buffered, h)
