@@ -46,7 +46,8 @@ BASE_LEVEL, BASE_DOFS = 7, 1089643  # the N = 1 workload: level-7 cylinder mesh
 BIG_LEVEL, BIG_DOFS = 16, 10644763  # the "~10 M DoF" mesh of BASELINE.json configs[3] (level 14 has 7.3 M)
 if os.environ.get("NSX_BENCH_BIG_LEVEL"):  # development only: rehearse the strong_10M leg's control flow on a small mesh
     BIG_LEVEL, BIG_DOFS = int(os.environ["NSX_BENCH_BIG_LEVEL"]), None
-BIG_STEPS, BIG_WARMUP, BIG_SPINUP = 10, 2, 5  # schedule of the strong_10M leg: the same on one GPU (committed base) and on N
+BIG_STEPS, BIG_WARMUP, BIG_SPINUP = 6, 1, 3  # schedule of the strong_10M leg: the same on one GPU (committed base) and on N (short: at N = 2 a step of
+                                             # this mesh still takes seconds, and the whole invocation has to stay within minutes)
 PMC_PROFILE = "profiles/r04_pmc_fetch_write_per_kernel.json"
 LAYOUT_PROFILE = "profiles/r04_layout_iterations.json"
 BIG_BASE_PROFILE = "profiles/r04_strong_10M_one_gpu.json"
@@ -625,7 +626,7 @@ def main():
     steps, warmup = (args.steps, args.warmup) if not args.cpu_only else (2, 1)
     # ---- the headline: ONE mesh (1 089 643 DoF unless --level says otherwise) on N GPUs, plain time-steps/s
     elapsed, stats, table, prof_stats, state, dofs = partitioned_run(level, steps, warmup, args.spinup, 0 if args.cpu_only else args.profile_steps,
-                                                                     want_state=(world == 1 and not args.no_cpu), twin=(world == 1 and not args.cpu_only))
+                                                                     want_state=(world == 1 and not args.no_cpu), twin=(world == 1 and not args.cpu_only and args.level is None))
     value = steps / elapsed
     big = None
     if world > 1 and args.level is None and not args.no_big:
