@@ -628,22 +628,55 @@ def main():
     elapsed, stats, table, prof_stats, state, dofs = partitioned_run(level, steps, warmup, args.spinup, 0 if args.cpu_only else args.profile_steps,
                                                                      want_state=(world == 1 and not args.no_cpu), twin=(world == 1 and not args.cpu_only and args.level is None))
     value = steps / elapsed
-    big = None
-    if world > 1 and args.level is None and not args.no_big:
-        # ---- strong_10M: the 10 644 763-DoF mesh partitioned over the N GPUs, the schedule of its committed one-GPU base
-        el_b, stats_b, _, _, _, dofs_b = partitioned_run(BIG_LEVEL, BIG_STEPS, BIG_WARMUP, BIG_SPINUP, 0)
+    run_big = world > 1 and args.level is None and not args.no_big
+
+    def big_leg(on_deadline):
+        """strong_10M: the 10 644 763-DoF mesh partitioned over the N GPUs, the schedule of its committed one-GPU base.  The headline of
+        this invocation is already measured when this leg starts: a rank that fails here, or a leg that outlives its deadline
+        (NSX_BENCH_BIG_DEADLINE seconds), is REPORTED under "strong_10M" instead of taking the measured line with it"""
+        import threading
+        deadline = float(os.environ.get("NSX_BENCH_BIG_DEADLINE", "900"))
+        finished = threading.Event()
+        failure = []
+
+        def watchdog():
+            if not finished.wait(deadline):
+                on_deadline({"error": failure[0] if failure else "not finished after %.0f s (NSX_BENCH_BIG_DEADLINE)" % deadline, "n_gpus": world})
+                os._exit(0)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            n_ranks = total_ranks(args, BIG_DOFS) if BIG_DOFS else args.ranks * world
+            beat("level %d: building the mesh and the caller's DoF table" % BIG_LEVEL, every=0.0)
+            _, dofs_b, tables_b = build_problem(BIG_LEVEL, n_ranks, world, args.ordering, args.balance, args.numbering, args.ranks_input)
+            el_b, stats_b, _, _, _ = gpu_run(dofs_b, tables_b, BIG_STEPS, BIG_WARMUP, args.schur_blocks, local_rank, profile_steps=0, barrier=barrier,
+                                             rank=rank, world=world, spinup=BIG_SPINUP, layout=layout_of(args, dofs_b, world))
+            el_b = max_over_ranks(el_b)
+        except Exception as e:  # noqa: BLE001
+            failure.append("rank %d: %s: %s" % (rank, type(e).__name__, e))
+            print("bench.py: strong_10M leg failed on " + failure[0], file=sys.stderr, flush=True)
+            # the peers are blocked inside a collective and an exit code here would make the launcher end rank 0 before it has written the
+            # measured line: wait for the deadline, at which every rank leaves by itself
+            while True:
+                time.sleep(1.0)
+        finished.set()
         outer_b = sum(s["outer_iterations"] for s in stats_b)
         big = {"time_steps_per_s": BIG_STEPS / el_b, "ms_per_step": 1e3 * el_b / BIG_STEPS, "n_dofs": dofs_b.n_dofs, "n_gpus": world,
                "steps": BIG_STEPS, "warmup": BIG_WARMUP, "spinup_steps": BIG_SPINUP,
                "gmres_outer_iters_per_step": outer_b / float(BIG_STEPS), "ms_per_outer_iteration": 1e3 * el_b / max(1, outer_b),
                "allreduces_per_step": stats_b[0].get("allreduces_per_step"), "ghost_exchanges_per_step": stats_b[0].get("ghost_exchanges_per_step"),
+               "persistent_fallbacks": max(s.get("persistent_fallbacks", 0) for s in stats_b),
                "dof_steps_per_s_in_units_of_the_1M_mesh": BIG_STEPS / el_b * dofs_b.n_dofs / BASE_DOFS}
         base = committed_big_base()
         if base and base.get("n_dofs") == dofs_b.n_dofs:  # (not in a rehearsal of this leg on another mesh)
             big["one_gpu_base"] = base
             big["speedup_over_one_gpu"] = big["time_steps_per_s"] / base["value"] if base.get("value") else None
             big["speedup_per_outer_iteration"] = base["ms_per_outer_iteration"] / big["ms_per_outer_iteration"] if base.get("ms_per_outer_iteration") else None
+        return big
+
     if rank != 0:
+        if run_big:
+            big_leg(lambda err: None)
         if world > 1:
             torch.distributed.destroy_process_group()
         return
@@ -732,16 +765,19 @@ def main():
                            "note": "per-kernel HIP-event pass over separate steps (not the timed ones); compare kernel_ms_per_step with "
                                    "ms_per_step x outer_iters_per_step / gmres_outer_iters_per_step"},
     }
-    if big:
-        out["strong_10M"] = big
     if world > 1:
         out["strong_1M"] = {"time_steps_per_s": value, "n_dofs": dofs.n_dofs, "note": "= value: the mesh of the N = 1 line on %d GPUs" % world}
-    if out["persistent_fallbacks"]:
+    if out["persistent_fallbacks"] and world == 1:  # (N > 1: reported in the line — the launch-per-operation path is a legitimate, slower, distributed path)
         sys.exit("bench.py: %d persistent kernel(s) timed out and fell back to the launch-per-operation path: this is not the measured configuration"
                  % out["persistent_fallbacks"])
     layouts = committed_layouts()
     if layouts:
         out["preconditioner_layouts"] = layouts
+    if run_big:
+        def headline_only(err):
+            out["strong_10M"] = err
+            emit(out)
+        out["strong_10M"] = big_leg(headline_only)
     if world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(dofs, state, local_rank)
         # lead with the stronger CPU code (compact storage, same algorithm): the stated baseline is the reference-shaped one

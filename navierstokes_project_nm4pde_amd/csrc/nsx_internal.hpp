@@ -183,6 +183,12 @@ struct SpmvBlocked {
   DevBuf<int32_t> cptr, ucols;
   DevBuf<uint16_t> lidx;
   double ucols_total = 0;
+  // launch order: desc[4 * block] = {first staged column, staged columns, first row, end row} of the chunk workgroup `block` takes
+  // (grid = 8 * blocks per XCD; {0, 0, 0, 0} pads).  Workgroup b runs on XCD b % 8: every XCD gets a CONTIGUOUS range of chunks (their
+  // x entries meet in one L2) holding an eighth of the non-zeros, and takes them largest first, so the last workgroups to start are the short ones
+  DevBuf<int32_t> desc;
+  int grid = 0;
+  std::vector<int32_t> order;  // host copy: chunk of every block, -1 = padding
 };
 
 // Persistent Schur-complement CG (nsx_cg.hip): negative_S_tilde as slabs of 256 slots per Schur ILU block, 16-bit columns

@@ -278,6 +278,39 @@ void build_blocked(nsx_handle *h, const Csr &g, const std::vector<int32_t> &boun
     b.max_ucols = std::max<int>(b.max_ucols, (int)tmp.size());
   }
   b.ucols_total = (double)ucols.size();
+  {
+    // XCD k takes the chunks [cut[k], cut[k+1]): boundaries where the running non-zero count passes k / 8 of the total
+    const int64_t total = g.rowptr[bounds[b.n_chunks]] - g.rowptr[bounds[0]];
+    int cut[9];
+    cut[0] = 0;
+    for (int k = 1, c = 0; k <= 8; ++k) {
+      while (c < b.n_chunks && (int64_t)(g.rowptr[bounds[c + 1]] - g.rowptr[bounds[0]]) * 8 <= total * k) ++c;
+      cut[k] = k == 8 ? b.n_chunks : c;
+    }
+    int per_xcd = 0;
+    for (int k = 0; k < 8; ++k) per_xcd = std::max(per_xcd, cut[k + 1] - cut[k]);
+    b.grid = 8 * per_xcd;
+    b.order.assign((size_t)b.grid, -1);
+    std::vector<int32_t> desc((size_t)b.grid * 4, 0), list;
+    static const bool largest_first = !(getenv("NSX_SPMV_ORDER") && atoi(getenv("NSX_SPMV_ORDER")) == 0);
+    for (int k = 0; k < 8; ++k) {
+      list.resize((size_t)(cut[k + 1] - cut[k]));
+      for (size_t j = 0; j < list.size(); ++j) list[j] = cut[k] + (int)j;
+      if (largest_first)
+        std::stable_sort(list.begin(), list.end(), [&](int32_t a, int32_t c) {
+          return g.rowptr[bounds[a + 1]] - g.rowptr[bounds[a]] > g.rowptr[bounds[c + 1]] - g.rowptr[bounds[c]];
+        });
+      for (size_t j = 0; j < list.size(); ++j) {
+        const int blk = (int)j * 8 + k, c = list[j];
+        b.order[blk] = c;
+        desc[4 * (size_t)blk + 0] = cptr[c];
+        desc[4 * (size_t)blk + 1] = cptr[c + 1] - cptr[c];
+        desc[4 * (size_t)blk + 2] = bounds[c];
+        desc[4 * (size_t)blk + 3] = bounds[c + 1];
+      }
+    }
+    b.desc.upload(desc, h->stream);
+  }
   b.crow.upload(bounds, h->stream);
   b.cptr.upload(cptr, h->stream);
   b.ucols.upload(ucols, h->stream);

@@ -136,33 +136,107 @@ __global__ __launch_bounds__(256) void k_spmv_csr(int n_rows, const int32_t *__r
   if (lane == 0) y[row] = acc;
 }
 
+#ifdef NSX_SPMV_TRACE  // development only (tools/spmv_trace.sh): wall-clock stamps of every workgroup of ONE launch of the LDS-staged SpMV
+__device__ unsigned long long *g_spmv_trace = nullptr;
+__device__ int g_spmv_dbg = 0;  // what the traced launch leaves out: 1 the x gathers, 2 gathers from consecutive addresses, 3 the matrix stream, 4 all of the staging
+#define SPMV_DBG (g_spmv_trace ? g_spmv_dbg : 0)
+#define SPMV_STAMP(k)                                                                              \
+  do {                                                                                             \
+    if (g_spmv_trace && threadIdx.x == 0) g_spmv_trace[(size_t)blockIdx.x * 4 + (k)] = wall_clock64(); \
+  } while (0)
+#else
+#define SPMV_DBG 0
+#define SPMV_STAMP(k) \
+  do {                \
+  } while (0)
+#endif
+
 // LDS-staged SpMV: y[i][c] = sum_j A[i,j] x[j][c] with the chunk's x entries gathered ONCE into LDS (SpmvBlocked).
 // The per-non-zero stream is 8 B value + 2 B local column; the 24-B gathers of the plain kernel (10 M per product,
 // bound by the per-CU address rate, not by bytes) become ~1.5 M staged gathers + LDS reads.
-template <int DIM, int W>
-__global__ __launch_bounds__(256) void k_spmv_blocked(int n_rows, int n_chunks, const int32_t *__restrict__ crow, const int32_t *__restrict__ rp, const uint16_t *__restrict__ lidx,
-                                                      const double *__restrict__ av, const int32_t *__restrict__ cptr,
-                                                      const int32_t *__restrict__ ucols, const double *__restrict__ x,
+template <int DIM, int W, bool SEG>
+__global__ __launch_bounds__(256) void k_spmv_blocked(int n_rows, const int32_t *__restrict__ desc, const int32_t *__restrict__ rp, const uint16_t *__restrict__ lidx,
+                                                      const double *__restrict__ av, const int32_t *__restrict__ ucols, const double *__restrict__ x,
                                                       double *__restrict__ y) {
   extern __shared__ double xs[];
   __shared__ int rps[449];
-  // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs; XCD k takes the k-th contiguous eighth of the chunks,
-  // so the x entries its chunks stage (neighbouring chunks share most of them) stay in ONE 4-MiB L2 instead of being fetched
-  // into all eight (x is 8 MB at 1 M DoF: every L2 used to miss on it).  Grid = 8 * ceil(n_chunks / 8); speed only.
-  const int per_xcd = gridDim.x >> 3;
-  const int chunk = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if (chunk >= n_chunks) return;
-  const int c0 = cptr[chunk], nu = cptr[chunk + 1] - c0;
-  const int r0 = crow[chunk], r1 = crow[chunk + 1];
+  // launch order (SpmvBlocked::desc): workgroups are dealt round-robin over the 8 XCDs and XCD k takes a contiguous range of chunks, so
+  // the x entries its chunks stage (neighbouring chunks share most of them) stay in ONE 4-MiB L2 instead of being fetched into all
+  // eight (x is 8 MB at 1 M DoF); inside an XCD the chunks with the most non-zeros start first.  Speed only.
+  const int4 d = reinterpret_cast<const int4 *>(desc)[blockIdx.x];
+  const int c0 = d.x, nu = d.y, r0 = d.z, r1 = d.w;
+  if (r1 <= r0) return;
+  SPMV_STAMP(0);
+  [[maybe_unused]] const int dbg = SPMV_DBG;
   for (int t = threadIdx.x; t <= r1 - r0; t += 256) rps[t] = rp[r0 + t];
-  for (int t = threadIdx.x; t < nu; t += 256) {
-    const double *xj = x + (size_t)ucols[c0 + t] * DIM;
+  for (int t = threadIdx.x; t < nu && dbg != 4; t += 256) {
+    const int u = dbg == 2 ? (c0 + t) % n_rows : ucols[c0 + t];
+    const double *xj = x + (size_t)u * DIM;
 #pragma unroll
-    for (int c = 0; c < DIM; ++c) xs[t * DIM + c] = xj[c];
+    for (int c = 0; c < DIM; ++c) xs[t * DIM + c] = dbg == 1 ? (double)u : xj[c];
   }
   __syncthreads();
+  SPMV_STAMP(1);
   constexpr int G = 256 / W, U = 4;  // rows in flight per pass, loads per lane kept in flight
   const int grp = threadIdx.x / W, lane = threadIdx.x % W;
+  if constexpr (SEG) {
+    // Software pipeline over SEGMENTS of 2 W entries instead of whole rows: a row of the P2 graph has 19, 27 or 45-75 non-zeros (43 %,
+    // 43 %, 13 % of the rows), so 4 W load slots per row are 39 % full; with 2 W per segment and four segments in flight a lane has the
+    // same eight value + eight index loads outstanding, 70 % of them filled (profiles/r04_spmv_workgroup_timeline.txt: the product is
+    // bound by the bytes a CU keeps in flight).  A lane adds its entries in the same order as before (lane, lane + W, lane + 2 W, ...)
+    // and the group sum comes at the row's last segment: the same sums.
+    constexpr int US = 2, D = 4, SL = US * W;
+    double va[D][US];
+    int vl[D][US], tag[D];  // tag = (row << 1) | last segment of its row; -1: nothing fetched
+    int nrow = SPMV_DBG == 3 ? r1 : r0 + grp, noff = 0;
+    auto issue = [&](double (&a_)[US], int (&l_)[US], int &tg) {
+      const bool live = nrow < r1;
+      const int base = live ? rps[nrow - r0] : 0, len = live ? rps[nrow - r0 + 1] - base : 0;
+      const int p0 = base + noff + lane, e = base + min(len, noff + SL);
+#pragma unroll
+      for (int k = 0; k < US; ++k) {
+        const int q = p0 + k * W;
+        const bool ok = q < e;
+        a_[k] = ok ? ld_stream<2>(av + q) : 0.0;
+        l_[k] = ok ? (int)ld_stream<2>(lidx + q) : 0;
+      }
+      const bool last = noff + SL >= len;
+      tg = live ? ((nrow << 1) | (int)last) : -1;
+      noff = last ? 0 : noff + SL;
+      nrow = (live && last) ? nrow + G : nrow;
+    };
+    double acc[DIM];
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) acc[c] = 0.0;
+    auto eat = [&](const double (&a_)[US], const int (&l_)[US], int tg) {
+      if (tg < 0) return;
+#pragma unroll
+      for (int k = 0; k < US; ++k) {
+        const double *xj = xs + l_[k] * DIM;
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) acc[c] += a_[k] * xj[c];
+      }
+      double sum[DIM];
+#pragma unroll
+      for (int c = 0; c < DIM; ++c) sum[c] = group_sum<W>(acc[c]);
+      const bool last = tg & 1;
+      if (last && lane == 0) {
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) y[(size_t)(tg >> 1) * DIM + c] = sum[c];
+      }
+#pragma unroll
+      for (int c = 0; c < DIM; ++c) acc[c] = last ? 0.0 : acc[c];
+    };
+#pragma unroll
+    for (int i = 0; i < D; ++i) issue(va[i], vl[i], tag[i]);
+    while (tag[0] >= 0) {
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        eat(va[i], vl[i], tag[i]);
+        issue(va[i], vl[i], tag[i]);
+      }
+    }
+  } else {
   // software pipeline over the rows of this lane group: the loads of the next row are issued before the current row is
   // reduced, so a wave always has 2*U value loads + 2*U index loads outstanding instead of one dependent chain per row
   double a[U], na[U];
@@ -205,6 +279,7 @@ __global__ __launch_bounds__(256) void k_spmv_blocked(int n_rows, int n_chunks, 
     }
   };
   // two register sets, no moves: while one row is reduced the loads of the next two are in flight
+  if (SPMV_DBG == 3) row = r1;
   fetch(row, a, l);
   fetch(row + G, na, nl);
   for (; row < r1; row += 2 * G) {
@@ -213,6 +288,17 @@ __global__ __launch_bounds__(256) void k_spmv_blocked(int n_rows, int n_chunks, 
     consume(row + G, na, nl);
     fetch(row + 3 * G, na, nl);
   }
+  }
+#ifdef NSX_SPMV_TRACE
+  __syncthreads();
+  SPMV_STAMP(2);
+  if (g_spmv_trace && threadIdx.x == 0) {
+    unsigned xcc, id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id));
+    g_spmv_trace[(size_t)blockIdx.x * 4 + 3] = ((unsigned long long)xcc << 32) | id;
+  }
+#endif
 }
 
 static double bytes_vel(nsx_handle *h, bool with_g) {
@@ -268,13 +354,50 @@ static bool launch_blocked(nsx_handle *h, const double *vals, const double *x, d
   if (!blocked || b.n_chunks == 0 || b.max_rows > 448) return false;
   const size_t shm = (size_t)b.max_ucols * h->dim * sizeof(double);
   if (shm > 64 * 1024) return false;
-  const int grid = 8 * cdiv(b.n_chunks, 8);
-  if (h->dim == 2)
-    hipLaunchKernelGGL((k_spmv_blocked<2, 16>), dim3(grid), dim3(256), shm, h->stream, h->N2, b.n_chunks, b.crow.p, h->gA.rowptr.p, b.lidx.p, vals,
-                       b.cptr.p, b.ucols.p, x, y);
-  else
-    hipLaunchKernelGGL((k_spmv_blocked<3, 16>), dim3(grid), dim3(256), shm, h->stream, h->N2, b.n_chunks, b.crow.p, h->gA.rowptr.p, b.lidx.p, vals,
-                       b.cptr.p, b.ucols.p, x, y);
+  const int grid = b.grid;
+  static const bool seg = getenv("NSX_SPMV_SEG") && atoi(getenv("NSX_SPMV_SEG")) != 0;  // 1: the segment pipeline (being measured)
+#define NSX_BLK(D)                                                                                                                                   \
+  do {                                                                                                                                               \
+    if (seg)                                                                                                                                         \
+      hipLaunchKernelGGL((k_spmv_blocked<D, 16, true>), dim3(grid), dim3(256), shm, h->stream, h->N2, b.desc.p, h->gA.rowptr.p, b.lidx.p, vals,      \
+                         b.ucols.p, x, y);                                                                                                           \
+    else                                                                                                                                             \
+      hipLaunchKernelGGL((k_spmv_blocked<D, 16, false>), dim3(grid), dim3(256), shm, h->stream, h->N2, b.desc.p, h->gA.rowptr.p, b.lidx.p, vals,     \
+                         b.ucols.p, x, y);                                                                                                           \
+  } while (0)
+#ifdef NSX_SPMV_TRACE
+  static int n_call = 0;
+  const bool traced = getenv("NSX_SPMV_TRACE_OUT") && ++n_call == (getenv("NSX_SPMV_TRACE_CALL") ? atoi(getenv("NSX_SPMV_TRACE_CALL")) : 5000);
+  for (int mode = 0; traced && mode <= 4; ++mode) {  // every variant once, traced; the untraced launch below leaves the right y behind
+    unsigned long long *tr = nullptr;
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipMalloc(&tr, (size_t)grid * 4 * sizeof(unsigned long long));
+    (void)hipMemset(tr, 0, (size_t)grid * 4 * sizeof(unsigned long long));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_spmv_trace), &tr, sizeof(tr));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_spmv_dbg), &mode, sizeof(mode));
+    if (h->dim == 2) NSX_BLK(2); else NSX_BLK(3);
+    (void)hipStreamSynchronize(h->stream);
+    std::vector<unsigned long long> host((size_t)grid * 4);
+    (void)hipMemcpy(host.data(), tr, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    unsigned long long *none = nullptr;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_spmv_trace), &none, sizeof(none));
+    (void)hipFree(tr);
+    const std::string path = std::string(getenv("NSX_SPMV_TRACE_OUT")) + "_mode" + std::to_string(mode) + ".txt";
+    if (FILE *f = fopen(path.c_str(), "w")) {
+      fprintf(f, "# block chunk rows ucols t_start t_staged t_end xcc hw_id   (wall_clock64 ticks of 10 ns)\n");
+      std::vector<int32_t> ds((size_t)grid * 4);
+      (void)hipMemcpy(ds.data(), b.desc.p, ds.size() * 4, hipMemcpyDeviceToHost);
+      for (int blk = 0; blk < grid; ++blk) {
+        if (b.order[blk] < 0) continue;
+        fprintf(f, "%d %d %d %d %llu %llu %llu %llu %llu\n", blk, b.order[blk], ds[4 * (size_t)blk + 3] - ds[4 * (size_t)blk + 2], ds[4 * (size_t)blk + 1],
+                host[4 * (size_t)blk], host[4 * (size_t)blk + 1], host[4 * (size_t)blk + 2], host[4 * (size_t)blk + 3] >> 32, host[4 * (size_t)blk + 3] & 0xffffffffull);
+      }
+      fclose(f);
+    }
+  }
+#endif
+  if (h->dim == 2) NSX_BLK(2); else NSX_BLK(3);
+#undef NSX_BLK
   return true;
 }
 

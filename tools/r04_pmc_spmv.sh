@@ -1,0 +1,26 @@
+#!/bin/bash
+# development tool (round 4), on the GPU box: load-path counters of the LDS-staged SpMV (one rocprofv3 --pmc pass per counter group)
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --list-avail > $OUT/pmc_list_avail.txt 2>&1 || true
+i=0
+for G in "$@"; do
+  i=$((i+1))
+  rocprofv3 --pmc $G --kernel-trace --output-format csv -d $OUT/pmc_spmv_$i -- python3 $R/bench.py --steps 1 --warmup 1 --spinup 2 --no-cpu --profile-steps 0 --pmc off > $OUT/pmc_spmv_$i.json 2> $OUT/pmc_spmv_$i.err || { echo "group $i ($G) failed"; tail -3 $OUT/pmc_spmv_$i.err; continue; }
+  python3 - "$OUT/pmc_spmv_$i" "$G" <<'PY'
+import csv, glob, sys, collections
+d, names = sys.argv[1], sys.argv[2]
+f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for row in csv.DictReader(open(f[0])):
+    k = row["Kernel_Name"]
+    for key in ("k_spmv_blocked", "k_ilu_solve_lanes", "k_mgs_one<8", "k_axpy_multi", "k_spmv_vel"):
+        if key in k:
+            acc[key][row["Counter_Name"]].append(float(row["Counter_Value"]))
+for key, cs in acc.items():
+    print(key, {c: (round(sum(v) / len(v), 1), len(v)) for c, v in cs.items()})
+PY
+  rm -rf $OUT/pmc_spmv_$i
+done
