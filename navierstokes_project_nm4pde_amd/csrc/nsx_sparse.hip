@@ -154,7 +154,7 @@ __device__ int g_spmv_dbg = 0;  // what the traced launch leaves out: 1 the x ga
 // LDS-staged SpMV: y[i][c] = sum_j A[i,j] x[j][c] with the chunk's x entries gathered ONCE into LDS (SpmvBlocked).
 // The per-non-zero stream is 8 B value + 2 B local column; the 24-B gathers of the plain kernel (10 M per product,
 // bound by the per-CU address rate, not by bytes) become ~1.5 M staged gathers + LDS reads.
-template <int DIM, int W, bool SEG>
+template <int DIM, int W>
 __global__ __launch_bounds__(256) void k_spmv_blocked(int n_rows, const int32_t *__restrict__ desc, const int32_t *__restrict__ rp, const uint16_t *__restrict__ lidx,
                                                       const double *__restrict__ av, const int32_t *__restrict__ ucols, const double *__restrict__ x,
                                                       double *__restrict__ y) {
@@ -179,64 +179,6 @@ __global__ __launch_bounds__(256) void k_spmv_blocked(int n_rows, const int32_t 
   SPMV_STAMP(1);
   constexpr int G = 256 / W, U = 4;  // rows in flight per pass, loads per lane kept in flight
   const int grp = threadIdx.x / W, lane = threadIdx.x % W;
-  if constexpr (SEG) {
-    // Software pipeline over SEGMENTS of 2 W entries instead of whole rows: a row of the P2 graph has 19, 27 or 45-75 non-zeros (43 %,
-    // 43 %, 13 % of the rows), so 4 W load slots per row are 39 % full; with 2 W per segment and four segments in flight a lane has the
-    // same eight value + eight index loads outstanding, 70 % of them filled (profiles/r04_spmv_workgroup_timeline.txt: the product is
-    // bound by the bytes a CU keeps in flight).  A lane adds its entries in the same order as before (lane, lane + W, lane + 2 W, ...)
-    // and the group sum comes at the row's last segment: the same sums.
-    constexpr int US = 2, D = 4, SL = US * W;
-    double va[D][US];
-    int vl[D][US], tag[D];  // tag = (row << 1) | last segment of its row; -1: nothing fetched
-    int nrow = SPMV_DBG == 3 ? r1 : r0 + grp, noff = 0;
-    auto issue = [&](double (&a_)[US], int (&l_)[US], int &tg) {
-      const bool live = nrow < r1;
-      const int base = live ? rps[nrow - r0] : 0, len = live ? rps[nrow - r0 + 1] - base : 0;
-      const int p0 = base + noff + lane, e = base + min(len, noff + SL);
-#pragma unroll
-      for (int k = 0; k < US; ++k) {
-        const int q = p0 + k * W;
-        const bool ok = q < e;
-        a_[k] = ok ? ld_stream<2>(av + q) : 0.0;
-        l_[k] = ok ? (int)ld_stream<2>(lidx + q) : 0;
-      }
-      const bool last = noff + SL >= len;
-      tg = live ? ((nrow << 1) | (int)last) : -1;
-      noff = last ? 0 : noff + SL;
-      nrow = (live && last) ? nrow + G : nrow;
-    };
-    double acc[DIM];
-#pragma unroll
-    for (int c = 0; c < DIM; ++c) acc[c] = 0.0;
-    auto eat = [&](const double (&a_)[US], const int (&l_)[US], int tg) {
-      if (tg < 0) return;
-#pragma unroll
-      for (int k = 0; k < US; ++k) {
-        const double *xj = xs + l_[k] * DIM;
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) acc[c] += a_[k] * xj[c];
-      }
-      double sum[DIM];
-#pragma unroll
-      for (int c = 0; c < DIM; ++c) sum[c] = group_sum<W>(acc[c]);
-      const bool last = tg & 1;
-      if (last && lane == 0) {
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) y[(size_t)(tg >> 1) * DIM + c] = sum[c];
-      }
-#pragma unroll
-      for (int c = 0; c < DIM; ++c) acc[c] = last ? 0.0 : acc[c];
-    };
-#pragma unroll
-    for (int i = 0; i < D; ++i) issue(va[i], vl[i], tag[i]);
-    while (tag[0] >= 0) {
-#pragma unroll
-      for (int i = 0; i < D; ++i) {
-        eat(va[i], vl[i], tag[i]);
-        issue(va[i], vl[i], tag[i]);
-      }
-    }
-  } else {
   // software pipeline over the rows of this lane group: the loads of the next row are issued before the current row is
   // reduced, so a wave always has 2*U value loads + 2*U index loads outstanding instead of one dependent chain per row
   double a[U], na[U];
@@ -287,7 +229,6 @@ __global__ __launch_bounds__(256) void k_spmv_blocked(int n_rows, const int32_t 
     fetch(row + 2 * G, a, l);
     consume(row + G, na, nl);
     fetch(row + 3 * G, na, nl);
-  }
   }
 #ifdef NSX_SPMV_TRACE
   __syncthreads();
@@ -355,16 +296,8 @@ static bool launch_blocked(nsx_handle *h, const double *vals, const double *x, d
   const size_t shm = (size_t)b.max_ucols * h->dim * sizeof(double);
   if (shm > 64 * 1024) return false;
   const int grid = b.grid;
-  static const bool seg = getenv("NSX_SPMV_SEG") && atoi(getenv("NSX_SPMV_SEG")) != 0;  // 1: the segment pipeline (being measured)
-#define NSX_BLK(D)                                                                                                                                   \
-  do {                                                                                                                                               \
-    if (seg)                                                                                                                                         \
-      hipLaunchKernelGGL((k_spmv_blocked<D, 16, true>), dim3(grid), dim3(256), shm, h->stream, h->N2, b.desc.p, h->gA.rowptr.p, b.lidx.p, vals,      \
-                         b.ucols.p, x, y);                                                                                                           \
-    else                                                                                                                                             \
-      hipLaunchKernelGGL((k_spmv_blocked<D, 16, false>), dim3(grid), dim3(256), shm, h->stream, h->N2, b.desc.p, h->gA.rowptr.p, b.lidx.p, vals,     \
-                         b.ucols.p, x, y);                                                                                                           \
-  } while (0)
+#define NSX_BLK(D) \
+  hipLaunchKernelGGL((k_spmv_blocked<D, 16>), dim3(grid), dim3(256), shm, h->stream, h->N2, b.desc.p, h->gA.rowptr.p, b.lidx.p, vals, b.ucols.p, x, y)
 #ifdef NSX_SPMV_TRACE
   static int n_call = 0;
   const bool traced = getenv("NSX_SPMV_TRACE_OUT") && ++n_call == (getenv("NSX_SPMV_TRACE_CALL") ? atoi(getenv("NSX_SPMV_TRACE_CALL")) : 5000);
