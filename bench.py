@@ -23,8 +23,9 @@ rank, RCCL halo exchange of ghost DoFs inside every SpMV, RCCL all-reduce of eve
 as the reference's MPI run).  `value` is ALWAYS plain time-steps/s of the 1 089 643-DoF mesh of the N = 1 line ("scaling":
 "strong": value(N) / value(1) is the speed-up of that mesh).  The same invocation also partitions the 10 644 763-DoF mesh
 (level 16, BASELINE.json configs[3]) over the N GPUs and reports it under "strong_10M" beside its committed one-GPU base
-(profiles/r04_strong_10M_one_gpu.json): the >= 6x of SURVEY 8(d) is read from that entry.  A rank that fails makes the whole job
-exit non-zero; there is no fallback mode.
+(profiles/r04_strong_10M_one_gpu.json): the >= 6x of SURVEY 8(d) is read from that entry.  A rank that fails in the headline run
+makes the whole job exit non-zero; the strong_10M leg runs after the headline is measured, under a deadline, and a failure there is
+reported inside "strong_10M" instead of discarding the measured line.
 
 Other modes (not the driver's): --comm rccl1 (one GPU, 1-rank RCCL communicator: the distributed code path -- one launch + one
 ncclAllReduce per reduction -- timed on one card), --cpu-only (the cpu_baseline leg alone), --layout-table FILE (iteration counts
