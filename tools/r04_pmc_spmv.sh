@@ -1,5 +1,8 @@
 #!/bin/bash
 # development tool (round 4), on the GPU box: load-path counters of the LDS-staged SpMV (one rocprofv3 --pmc pass per counter group)
+#   bash tools/r04_pmc_spmv.sh "TA_BUSY_avr GRBM_GUI_ACTIVE" "MemUnitBusy MemUnitStalled" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"
+# (results: profiles/r04_spmv_workgroup_timeline.txt).  The group "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum
+# TA_DATA_STALLED_BY_TC_CYCLES_sum" never finished on this pool (the run was ended as silent after 7 minutes): leave it out.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
