@@ -15,7 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize("dim,level,world,n_sub,prec,ordering,schur_merge,layout_ranks",
                          [(3, 1, 2, 3, 0, "first_touch", 0, 0), (2, 2, 3, 2, 3, "first_touch", 0, 0),
                           (3, 1, 2, 4, 0, "colour", 2, 0),   # the options of rounds 1-3's bench: colour order, merged Schur blocks (dense inverses)
-                          (3, 2, 2, 1, 0, "first_touch", 0, 12)])  # round 4's bench: deal.II's numbering, one rank per GPU, the layout built inside every handle
+                          (3, 2, 2, 1, 0, "first_touch", 0, 12),   # round 4's bench: deal.II's numbering, one rank per GPU, the layout built inside every handle
+                          (3, 2, 4, 1, 0, "first_touch", 0, 6)])   # the same with four ranks: several neighbours per rank, 6 / 9 / 12 / 15 virtual ranks inside them
 def test_distributed_solve_equals_single_process(tmp_path, dim, level, world, n_sub, prec, ordering, schur_merge, layout_ranks):
     out = tmp_path / "dist.npz"
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
