@@ -132,18 +132,11 @@ __global__ void k_probe_wait(const unsigned long long *flag, int *seen) {
     if (wall_clock64() - t0 > 2000000ull) return;  // 20 ms
   }
 }
-// Do kernels of the communication stream run WHILE a kernel of the compute stream is waiting for them -- here, now, on every
-// rank?  A one-thread kernel on the compute stream waits (at most 20 ms) for a word that a one-thread kernel on the communication
-// stream stores; the ranks then take the minimum of their answers (one collective in the lifetime of a handle), so that all of
-// them use the collective-inside-the-grid sweep or none does.
-bool comm_streams_concurrent(nsx_handle *h) {
-  Comm *c = h->comm;
-  if (!c || !c->comm) return false;
-  ensure_comm_stream(h);
+// Do kernels of the communication stream run WHILE a kernel of the compute stream is waiting for them -- here, now?  A one-thread
+// kernel on the compute stream waits (at most 20 ms) for a word that a one-thread kernel on the communication stream stores.
+static bool probe_streams_local(nsx_handle *h) {
   DevBuf<unsigned long long> word;
-  DevBuf<double> ans;
   word.alloc(2);
-  ans.alloc(1);
   word.zero(h->stream);
   HIP_CHECK(hipStreamSynchronize(h->stream));
   HIP_CHECK(hipStreamSynchronize(h->comm_stream));
@@ -153,13 +146,43 @@ bool comm_streams_concurrent(nsx_handle *h) {
   HIP_CHECK(hipStreamSynchronize(h->stream));
   int seen = 0;
   HIP_CHECK(hipMemcpy(&seen, word.p + 1, sizeof(int), hipMemcpyDeviceToHost));
-  double v = seen ? 1.0 : 0.0;
+  return seen != 0;
+}
+// The runtime deals streams to a few hardware queues in the order of their creation, and two streams on one queue run in order: whether
+// the communication stream got a queue of its own depends on how many streams this process has created before (a second handle in
+// one process found itself on its compute stream's queue).  So the stream is created when the communicator is -- before anything
+// has been enqueued on it -- probed, and replaced by the next one the runtime hands out until the probe passes (at most 6 times).
+void comm_prepare_streams(nsx_handle *h) {
+  h->comm_probe_local = 0;
+  for (int attempt = 0; attempt < 6 && !h->comm_probe_local; ++attempt) {
+    ensure_comm_stream(h);
+    if (probe_streams_local(h)) {
+      h->comm_probe_local = 1;
+    } else {
+      (void)hipEventDestroy(h->ev_ready);
+      h->ev_ready = nullptr;
+      (void)hipStreamDestroy(h->comm_stream);
+      h->comm_stream = nullptr;
+    }
+  }
+  ensure_comm_stream(h);
+  if (getenv("NSX_DEBUG")) fprintf(stderr, "[nsx] communication stream runs beside a waiting compute kernel: %d\n", h->comm_probe_local);
+}
+// ... on every rank?  The ranks take the minimum of their answers (one collective in the lifetime of a handle), so that all of them
+// use the collective-inside-the-grid sweep or none does.
+bool comm_streams_concurrent(nsx_handle *h) {
+  Comm *c = h->comm;
+  if (!c || !c->comm) return false;
+  if (h->comm_probe_local < 0) comm_prepare_streams(h);
+  DevBuf<double> ans;
+  ans.alloc(1);
+  double v = h->comm_probe_local ? 1.0 : 0.0;
   HIP_CHECK(hipMemcpy(ans.p, &v, sizeof(double), hipMemcpyHostToDevice));
   h->n_allreduce++;
   NCCL_CHECK(ncclAllReduce(ans.p, ans.p, 1, ncclDouble, ncclMin, c->comm, h->stream));
   HIP_CHECK(hipStreamSynchronize(h->stream));
   HIP_CHECK(hipMemcpy(&v, ans.p, sizeof(double), hipMemcpyDeviceToHost));
-  if (getenv("NSX_DEBUG")) fprintf(stderr, "[nsx] communication stream runs beside a waiting compute kernel: here %d, on all ranks %d\n", seen, (int)(v > 0.5));
+  if (getenv("NSX_DEBUG")) fprintf(stderr, "[nsx] communication stream beside the compute stream: here %d, on all ranks %d\n", h->comm_probe_local, (int)(v > 0.5));
   return v > 0.5;
 }
 
@@ -272,6 +295,7 @@ void comm_destroy(nsx_handle *h) {
   h->ev_ready = nullptr;
   if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
   h->comm_stream = nullptr;
+  h->comm_probe_local = -1;
   if (!h->comm) return;
   if (h->comm->comm) (void)ncclCommDestroy(h->comm->comm);
   delete h->comm;
@@ -301,6 +325,7 @@ int nsx_comm_init(nsx_handle *h, int rank, int world, const uint8_t id[128]) {
     ncclUniqueId u;
     memcpy(&u, id, 128);
     NCCL_CHECK(ncclCommInitRank(&h->comm->comm, world, u, rank));
+    nsx::comm_prepare_streams(h);
     h->mgs_dist_state = -1;  // a new communicator: the paths the ranks choose together are chosen again
     h->mgs_dist_fit.clear();
     h->cgd_agreed = -1;

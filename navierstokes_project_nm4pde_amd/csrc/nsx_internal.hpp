@@ -308,6 +308,7 @@ struct nsx_handle {
   int mgs_ext_parity = 0;
   std::map<int, int> mgs_dist_fit;   // local vector length -> do ALL ranks' resident grids hold their vector of this role (agreed once per length)
   int cgd_agreed = -1;               // two-launch Schur CG: -1 not decided for the current schedules, 0 / 1 the ranks' common answer
+  int comm_probe_local = -1;         // -1 not probed, 0 / 1: kernels of the communication stream run beside a waiting kernel of the compute stream (comm_prepare_streams)
   int mgs_dist_state = -1;           // -1 not decided yet, 0 two-pass sweep (mgs_lowsync), 1 the collective inside the persistent grid
   int mgs_max_wg_dist[3] = {0, 0, 0};  // resident-grid limits of the distributed instantiations (8 / 10 / 12 entries per thread), room left for the collective
   long long n_allreduce = 0, n_halo = 0;  // collectives issued (nsx_comm_counters)

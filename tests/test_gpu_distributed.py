@@ -181,3 +181,38 @@ def test_collective_inside_the_persistent_sweep_equals_the_two_pass_sweep():
     assert p2["fallbacks"] == 0 and p2["sweep_persistent"] and p2["dirty_mailbox_words"] == 0
     # the collective count is the two-pass sweep's (+ the one agreement of the ranks on the path, once per handle)
     assert abs(c2[0] - c1[0]) <= 2 + 0.01 * c1[0], (c1, c2)
+
+
+def test_time_out_of_the_sweep_with_the_collective_inside_falls_back_on_every_rank():
+    """The safety net of the default distributed sweep (NSX_GX_DROP_WG=1: one workgroup of the persistent grid never posts its sums,
+    which is what a grid that is not co-resident -- e.g. with RCCL's own kernel -- looks like): the reducers' count stays incomplete,
+    k_ext_wait raises the failure word, the all-reduce carries it to every rank, the grid ends without writing w, the handle
+    switches to the two-pass sweep for good and SAYS so.  Same iteration history and solution as the two-pass sweep."""
+    from navierstokes_project_nm4pde_amd import nsx
+    from navierstokes_project_nm4pde_amd.frontend import DoFs, Mesh, Tables
+    from navierstokes_project_nm4pde_amd.problem import InletVelocity, cylinder_boundary_values
+    mesh = Mesh.cylinder(3, 2).partition(1, 8)
+    dofs, tables = DoFs(mesh, "colour"), Tables(3)
+    out = []
+    for env in ({"NSX_MGS_DIST": "0"}, {"NSX_GX_DROP_WG": "1", "NSX_CG_PERSISTENT": "0"}):
+        os.environ.update(env)
+        try:
+            dev = nsx.Nsx(dofs, tables, 1e-3, 2e-4)
+            dev.comm_init_single()
+            dev.set_solution(np.zeros(dofs.n_dofs))
+            dev.assemble(nsx.TEMAM)
+            dev.apply_boundary_values(*cylinder_boundary_values(dofs, InletVelocity(3), 2e-4))
+            dev.profile(True)
+            st = dev.solve_time_step(nsx.ASIMPLE, tol_abs=1e-10, inner_rtol=1e-8)
+            out.append((st, dev.solution_owned.copy(), dev.profile_table(), dev.persistent_state()))
+            dev.close()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    (s0, x0, t0, p0), (s1, x1, t1, p1) = out
+    assert s0["status"] == 0 and s1["status"] == 0
+    for key in ("outer_iterations", "inner_F_iterations", "inner_S_iterations"):
+        assert abs(s0[key] - s1[key]) <= max(1, 0.02 * s0[key]), key
+    assert np.abs(x0 - x1).max() < 1e-9 * np.abs(x0).max()
+    assert p1["fallbacks"] >= 1 and not p1["sweep_persistent"]
+    assert t1.get("mgs_sweep", {}).get("launches", 0) >= 1 and t1.get("mgs_dots", {}).get("launches", 0) > 0   # one failed launch, two passes from then on
