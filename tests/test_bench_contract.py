@@ -1,0 +1,63 @@
+"""bench.py without a GPU: the committed evidence every bench line quotes is where bench.py looks for it and says what the
+code says (a kernel renamed without regenerating profiles/, a moved profile, a changed strong_10M schedule would otherwise
+only show up as nulls in a driver's record)."""
+import csv
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _bench():
+    import importlib
+    return importlib.import_module("bench")
+
+
+def test_committed_profiles_are_where_bench_reads_them():
+    b = _bench()
+    for rel in (b.PMC_PROFILE, b.LAYOUT_PROFILE, b.BIG_BASE_PROFILE, b.STEP_HISTORY):
+        assert os.path.isfile(os.path.join(ROOT, rel)), rel
+    base = b.committed_big_base()
+    assert base and base["n_dofs"] == b.BIG_DOFS and base["value"] > 0 and base["ms_per_outer_iteration"] > 0
+    # the one-GPU base was measured with the schedule the N > 1 leg uses
+    assert (base["steps"], base["warmup"], base["spinup_steps"]) == (b.BIG_STEPS, b.BIG_WARMUP, b.BIG_SPINUP)
+    mean = b.long_run_mean_outer()
+    assert mean and 15.0 < mean < 60.0
+    lay = b.committed_layouts()
+    assert lay and lay["rows"]
+
+
+def test_kernels_named_in_bench_exist_in_the_committed_profiles():
+    b = _bench()
+    with open(os.path.join(ROOT, b.PMC_PROFILE)) as f:
+        pmc = json.load(f)
+    with open(os.path.join(ROOT, "profiles", "r04_kernel_stats_bench_steps5.csv")) as f:
+        stats = [r["Name"] for r in csv.DictReader(f)]
+    for scope in ("spmv_F", "ilu_solve_F", "mgs_sweep", "cg_S"):
+        name = b.KERNEL_OF[scope]
+        assert name in pmc, (scope, name)
+        assert any(s.startswith(name + "(") for s in stats), (scope, name)
+        t, src = b.pmc_traffic(scope)
+        assert t and t > 1e6 and src == b.PMC_PROFILE, (scope, t, src)
+
+
+def test_committed_bench_line_carries_the_contract_fields():
+    with open(os.path.join(ROOT, "profiles", "r04_bench.json")) as f:
+        d = json.loads(f.read().strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "time-steps/s" and d["dtype"] == "f64" and d["n_gpus"] == 1 and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["traffic"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["cpu_model"] and "march=native" in c["compiler_flags"]
+    assert abs(d["ms_per_step"] * d["value"] - 1e3) < 1e-6 * 1e3
+
+
+def test_bench_help_runs_without_a_gpu():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "--gpus" in r.stdout and "--steps" in r.stdout and "--warmup" in r.stdout
