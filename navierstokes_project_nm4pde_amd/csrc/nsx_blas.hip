@@ -675,12 +675,13 @@ static_assert((size_t)MGS_ONE_VALS * MGS_MAX_WG + MGS_ONE_VALS <= MGS_BLK_REGION
 // removed > 99 % of the norm: decided from the global sums, i.e. alike on every rank) the grid leaves the LOCAL sum of |w'|^2 in
 // ext.norm_out, does not normalise and reports "norm pending": the host all-reduces that word (the second collective).
 constexpr int MGS_EXT_VALS = 64, MGS_EXT_FAIL = 63;
-constexpr unsigned long long GX_EXT_TIMEOUT_TICKS = 1000000000ull;  // 10 s at 100 MHz
+constexpr unsigned long long GX_EXT_TIMEOUT_TICKS = 100000000ull;  // 1 s at 100 MHz (a small collective takes tens of microseconds; its connections exist before the first sweep)
 struct MgsExt {
   double *vals;              // [MGS_EXT_VALS] this sweep's buffer: local totals, then (after the collective) the global ones
   double *vals_other;        // the other buffer: its failure word is cleared for the next sweep
   unsigned int *arrive;      // reducers that have delivered, cumulative over all sweeps
   unsigned long long *flag;  // sequence number of the last sweep whose collective is complete
+  unsigned long long *abort_seq;  // sequence number of the last sweep a workgroup gave up on: the verdict of the WHOLE grid (see the wait)
   double *norm_out;          // local |w'|^2 when the formula is refused
 };
 __device__ __forceinline__ double ext_ld(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -818,18 +819,30 @@ __global__ __launch_bounds__(256) void k_mgs_one(int n, int split, int gap, doub
   // ---- hop 2: everybody picks up the totals
   if constexpr (DIST) {
     if (threadIdx.x == 0) {  // the collective of this sweep is complete once the flag carries its sequence number
+      // A grid that gives up must give up as a whole.  The likely reason for a collective that does not come is that its kernel finds
+      // no place on the device WHILE this grid holds it (RCCL's generic kernel: 256 threads x 264 VGPRs; measured with a self-addressed
+      // send / receive, NSX_EXT_SELF_P2P): then the first workgroup that leaves makes room, the collective runs, and the workgroups
+      // still waiting would see the flag and go on to write w.  So the first one to time out records the sweep in abort_seq BEFORE it
+      // leaves, and a workgroup that sees the flag looks there before it believes it.
       unsigned long long t0 = 0;
       for (unsigned int spin = 1; __hip_atomic_load(ext.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seq; ++spin) {
         __builtin_amdgcn_s_sleep(1);
         if ((spin & 255u) == 0) {
+          if (__hip_atomic_load(ext.abort_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seq) {
+            s_err = 1;
+            break;
+          }
           const unsigned long long now = wall_clock64();
           if (t0 == 0) t0 = now;
           else if (now - t0 > GX_EXT_TIMEOUT_TICKS) {
+            __hip_atomic_store(ext.abort_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             s_err = 1;
             break;
           }
         }
       }
+      if (!s_err && __hip_atomic_load(ext.abort_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == seq) s_err = 1;
     }
     __syncthreads();
     for (int v = threadIdx.x; v < nvals; v += 256) tot[v] = ext_ld(ext.vals + v);
@@ -1057,7 +1070,7 @@ static void mgs_setup(nsx_handle *h) {
   }
   h->mgs_ext_vals.alloc(2 * MGS_EXT_VALS);
   h->mgs_ext_vals.zero(h->stream);
-  h->mgs_ext_words.alloc(2);
+  h->mgs_ext_words.alloc(3);
   h->mgs_ext_words.zero(h->stream);
   h->mgs_ext_expected = 0;
 }
@@ -1293,6 +1306,12 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
   const int n_inst = 3;  // the one-exchange sweep keeps a block of basis vectors in registers: 8, 10 or 12 entries per thread
   for (int k = 0; k < n_inst && h->mgs_max_wg; ++k) {
     const int es[3] = {8, 10, h->mgs_links == 0 ? 12 : 20};
+    // with the collective inside the grid only the 8-entry instantiation: it holds 246 VGPRs (248 allocated), so a CU that carries
+    // ONE of its workgroups keeps 264 registers per SIMD lane free -- exactly what a wave of RCCL's generic kernel needs (264; 256
+    // threads, 19.7 KB of LDS) -- and the grid limit leaves such CUs (mgs_setup).  The 10- and 12-entry instantiations allocate 256:
+    // RCCL's kernel finds no place beside them and the sweep times out (measured with a self-addressed send / receive in front of the
+    // collective, tools/r04_self_p2p.sh: level 5, 8 entries: 23.0 -> 30.9 us per sweep, no fallback; level 7, 10 entries: time-out)
+    if (dist && es[k] != 8) break;
     const int cap = dist ? h->mgs_max_wg_dist[k] : h->mgs_max_wg_e[k];
     if (cap <= 0) continue;
     nwg = std::max(1, std::min(cap, cdiv(n, 256 * 4)));
@@ -1300,7 +1319,7 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
     e_inst = es[k];
     if (per_thread <= es[k]) break;
   }
-  const int per_thread_max = h->mgs_links == 0 ? 12 : 20;
+  const int per_thread_max = dist ? 8 : h->mgs_links == 0 ? 12 : 20;
   if (dist) {
     // does the resident grid hold the vector -- on EVERY rank?  (local lengths differ; a rank on the two-pass sweep and a rank on the
     // persistent one would all-reduce differently laid-out buffers.)  Agreed once per vector length = per role of the solve.
@@ -1346,12 +1365,13 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
       int reset_words = reset_wg * reset_steps;
       double *gram_ = gram;
       double guard_ = mgs_norm_guard(h);
-      MgsExt ext{nullptr, nullptr, nullptr, nullptr, nullptr};
+      MgsExt ext{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
       if (dist) {
         ext.vals = h->mgs_ext_vals.p + (size_t)h->mgs_ext_parity * MGS_EXT_VALS;
         ext.vals_other = h->mgs_ext_vals.p + (size_t)(1 - h->mgs_ext_parity) * MGS_EXT_VALS;
         ext.flag = h->mgs_ext_words.p;
         ext.arrive = (unsigned int *)(h->mgs_ext_words.p + 1);
+        ext.abort_seq = h->mgs_ext_words.p + 2;
         ext.norm_out = h->scal.p + S_LS_NORM;
       }
       void *args[] = {&n_, &split, &gap, &w, &V, &dim_, &gram_, &box, &box_next, &reset_words, &sout, &err, &tail, &norm_, &consider_, &pub_vals, &pub_flag, &seq_, &drop_wg, &guard_, &ext};

@@ -193,6 +193,20 @@ void comm_ext_allreduce(nsx_handle *h, double *vals, int count, int fail_word, u
   ensure_comm_stream(h);
   h->n_allreduce++;
   hipLaunchKernelGGL(k_ext_wait, dim3(1), dim3(1), 0, h->comm_stream, arrive, expected, vals, fail_word);
+  // development (one-GPU boxes): a 1-rank all-reduce launches no kernel, so nothing of RCCL ever ran beside the persistent grid.  A
+  // send / receive pair addressed to this rank itself does launch RCCL's kernel (the same generic device kernel, the same resources):
+  // NSX_EXT_SELF_P2P=1 puts one in front of every collective of the sweep -- does it find a place while the grid holds the device?
+  static const bool self_p2p = getenv("NSX_EXT_SELF_P2P") && atoi(getenv("NSX_EXT_SELF_P2P")) != 0;
+  if (self_p2p) {
+    if (!h->ext_self.p) {
+      h->ext_self.alloc(2 * (size_t)count);
+      h->ext_self.zero(h->comm_stream);
+    }
+    NCCL_CHECK(ncclGroupStart());
+    NCCL_CHECK(ncclSend(h->ext_self.p, (size_t)count, ncclDouble, c->rank, c->comm, h->comm_stream));
+    NCCL_CHECK(ncclRecv(h->ext_self.p + count, (size_t)count, ncclDouble, c->rank, c->comm, h->comm_stream));
+    NCCL_CHECK(ncclGroupEnd());
+  }
   NCCL_CHECK(ncclAllReduce(vals, vals, count, ncclDouble, ncclSum, c->comm, h->comm_stream));
   hipLaunchKernelGGL(k_ext_release, dim3(1), dim3(1), 0, h->comm_stream, flag, seq);
 }

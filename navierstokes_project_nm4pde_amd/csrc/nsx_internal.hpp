@@ -303,11 +303,12 @@ struct nsx_handle {
   int gmres_depth = 0, ls_mode = -1;
   // the persistent sweep of a distributed run (k_mgs_one<.., true>): two value buffers used alternately, arrival counter, release flag
   nsx::DevBuf<double> mgs_ext_vals;
-  nsx::DevBuf<unsigned long long> mgs_ext_words;  // [0] release flag, [1] arrival counter (32 bits used)
+  nsx::DevBuf<unsigned long long> mgs_ext_words;  // [0] release flag, [1] arrival counter (32 bits used), [2] the sweep the grid gave up on
   unsigned int mgs_ext_expected = 0;
   int mgs_ext_parity = 0;
   std::map<int, int> mgs_dist_fit;   // local vector length -> do ALL ranks' resident grids hold their vector of this role (agreed once per length)
   int cgd_agreed = -1;               // two-launch Schur CG: -1 not decided for the current schedules, 0 / 1 the ranks' common answer
+  nsx::DevBuf<double> ext_self;           // development (NSX_EXT_SELF_P2P): operands of the self-addressed send / receive in front of the sweep's collective
   int comm_probe_local = -1;         // -1 not probed, 0 / 1: kernels of the communication stream run beside a waiting kernel of the compute stream (comm_prepare_streams)
   int mgs_dist_state = -1;           // -1 not decided yet, 0 two-pass sweep (mgs_lowsync), 1 the collective inside the persistent grid
   int mgs_max_wg_dist[3] = {0, 0, 0};  // resident-grid limits of the distributed instantiations (8 / 10 / 12 entries per thread), room left for the collective
