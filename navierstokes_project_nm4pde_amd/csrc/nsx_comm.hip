@@ -30,11 +30,33 @@ struct Comm {
     if (r_ != ncclSuccess) NSX_THROW(NSX_ERR_COMM, "%s failed: %s", #expr, ncclGetErrorString(r_));   \
   } while (0)
 
+// development (one-GPU boxes, NSX_EXT_SELF_P2P): a self-addressed send / receive pair = a REAL launch of RCCL's generic device kernel on
+// `st` (a 1-rank all-reduce launches none).  1: in front of the collective inside the Gram-Schmidt sweep (communication stream);
+// 2: in front of every all-reduce of the compute stream as well, so that RCCL kernels of ONE communicator alternate between two streams.
+static int self_p2p_mode() {
+  static const int m = getenv("NSX_EXT_SELF_P2P") ? atoi(getenv("NSX_EXT_SELF_P2P")) : 0;
+  return m;
+}
+static void self_p2p(nsx_handle *h, hipStream_t st) {
+  Comm *c = h->comm;
+  const size_t count = 64;
+  if (!h->ext_self.p) {
+    h->ext_self.alloc(4 * count);
+    h->ext_self.zero(st);
+  }
+  double *buf = h->ext_self.p + (st == h->stream ? 2 * count : 0);  // one pair of operands per stream
+  NCCL_CHECK(ncclGroupStart());
+  NCCL_CHECK(ncclSend(buf, count, ncclDouble, c->rank, c->comm, st));
+  NCCL_CHECK(ncclRecv(buf + count, count, ncclDouble, c->rank, c->comm, st));
+  NCCL_CHECK(ncclGroupEnd());
+}
+
 void comm_allreduce_scalars(nsx_handle *h, int slot0, int count) {
   Comm *c = h->comm;
   if (!c || (c->world == 1 && !c->comm)) return;  // a 1-rank RCCL communicator still runs the collective (API self-test)
   h->n_allreduce++;
   if (c->comm) {
+    if (self_p2p_mode() >= 2) self_p2p(h, h->stream);
     NCCL_CHECK(ncclAllReduce(h->scal.p + slot0, h->scal.p + slot0, count, ncclDouble, ncclSum, c->comm, h->stream));
   } else {
     HIP_CHECK(hipMemcpyAsync(h->scal_host + slot0, h->scal.p + slot0, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -50,6 +72,7 @@ void comm_allreduce_partials(nsx_handle *h, double *partials, int count) {
   if (!c || (c->world == 1 && !c->comm)) return;
   h->n_allreduce++;
   if (c->comm) {
+    if (self_p2p_mode() >= 2) self_p2p(h, h->stream);
     NCCL_CHECK(ncclAllReduce(partials, partials, count, ncclDouble, ncclSum, c->comm, h->stream));
   } else {
     c->stage.resize((size_t)count);
@@ -193,20 +216,7 @@ void comm_ext_allreduce(nsx_handle *h, double *vals, int count, int fail_word, u
   ensure_comm_stream(h);
   h->n_allreduce++;
   hipLaunchKernelGGL(k_ext_wait, dim3(1), dim3(1), 0, h->comm_stream, arrive, expected, vals, fail_word);
-  // development (one-GPU boxes): a 1-rank all-reduce launches no kernel, so nothing of RCCL ever ran beside the persistent grid.  A
-  // send / receive pair addressed to this rank itself does launch RCCL's kernel (the same generic device kernel, the same resources):
-  // NSX_EXT_SELF_P2P=1 puts one in front of every collective of the sweep -- does it find a place while the grid holds the device?
-  static const bool self_p2p = getenv("NSX_EXT_SELF_P2P") && atoi(getenv("NSX_EXT_SELF_P2P")) != 0;
-  if (self_p2p) {
-    if (!h->ext_self.p) {
-      h->ext_self.alloc(2 * (size_t)count);
-      h->ext_self.zero(h->comm_stream);
-    }
-    NCCL_CHECK(ncclGroupStart());
-    NCCL_CHECK(ncclSend(h->ext_self.p, (size_t)count, ncclDouble, c->rank, c->comm, h->comm_stream));
-    NCCL_CHECK(ncclRecv(h->ext_self.p + count, (size_t)count, ncclDouble, c->rank, c->comm, h->comm_stream));
-    NCCL_CHECK(ncclGroupEnd());
-  }
+  if (self_p2p_mode() >= 1) self_p2p(h, h->comm_stream);  // development: a real RCCL kernel beside the grid that waits for this collective
   NCCL_CHECK(ncclAllReduce(vals, vals, count, ncclDouble, ncclSum, c->comm, h->comm_stream));
   hipLaunchKernelGGL(k_ext_release, dim3(1), dim3(1), 0, h->comm_stream, flag, seq);
 }
