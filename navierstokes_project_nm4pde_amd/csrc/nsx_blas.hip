@@ -1066,6 +1066,8 @@ static void mgs_setup(nsx_handle *h) {
     HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mgs_one_fn(es_one[k], true), 256, 0));
     const int slots = per_cu * cus;
     h->mgs_max_wg_dist[k] = std::max(0, std::min(MGS_MAX_WG, slots - std::max(32, slots / 8)));
+    // on a compute stream that leaves one CU per XCD to the collective's kernel: every shader engine counts as the one that lost a CU
+    h->mgs_dist_cap_reserved[k] = std::max(0, std::min(MGS_MAX_WG, per_cu * (cus - 32)));
     if (getenv("NSX_MGS_MAXWG")) h->mgs_max_wg_dist[k] = std::max(1, std::min(h->mgs_max_wg_dist[k], atoi(getenv("NSX_MGS_MAXWG"))));
   }
   h->mgs_ext_vals.alloc(2 * MGS_EXT_VALS);
@@ -1311,15 +1313,43 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
     // threads, 19.7 KB of LDS) -- and the grid limit leaves such CUs (mgs_setup).  The 10- and 12-entry instantiations allocate 256:
     // RCCL's kernel finds no place beside them and the sweep times out (measured with a self-addressed send / receive in front of the
     // collective, tools/r04_self_p2p.sh: level 5, 8 entries: 23.0 -> 30.9 us per sweep, no fallback; level 7, 10 entries: time-out)
-    if (dist && es[k] != 8) break;
-    const int cap = dist ? h->mgs_max_wg_dist[k] : h->mgs_max_wg_e[k];
+    // ... unless the compute stream leaves one CU per XCD to the communication stream (comm_reserve_cus, below): then any instantiation
+    if (dist && es[k] != 8 && !h->cu_reserved) break;
+    const int cap = dist ? (h->cu_reserved ? h->mgs_dist_cap_reserved[k] : h->mgs_max_wg_dist[k]) : h->mgs_max_wg_e[k];
     if (cap <= 0) continue;
     nwg = std::max(1, std::min(cap, cdiv(n, 256 * 4)));
     per_thread = cdiv(n, (int64_t)nwg * 256);
     e_inst = es[k];
     if (per_thread <= es[k]) break;
   }
-  const int per_thread_max = dist ? 8 : h->mgs_links == 0 ? 12 : 20;
+  int per_thread_max = (dist && !h->cu_reserved) ? 8 : h->mgs_links == 0 ? 12 : 20;
+  if (dist && !h->cu_reserved && h->mgs_dist_fit.find(n) == h->mgs_dist_fit.end()) {
+    // too long for the 8-entry grid somewhere, but not for the larger instantiations on a masked compute stream?  NSX_COMM_CU_RESERVE:
+    // 0 never, 1 (default) when that is what keeps the collective inside the grid, 2 always.  Every rank takes the same steps.
+    static const int reserve = getenv("NSX_COMM_CU_RESERVE") ? atoi(getenv("NSX_COMM_CU_RESERVE")) : 1;
+    const bool fits8 = e_inst != 0 && per_thread <= 8;
+    bool fits_reserved = false;
+    for (int k = 0; k < 3 && !fits_reserved; ++k)
+      fits_reserved = h->mgs_dist_cap_reserved[k] > 0 &&
+                      cdiv(n, (int64_t)std::max(1, std::min(h->mgs_dist_cap_reserved[k], cdiv(n, 256 * 4))) * 256) <= (k == 0 ? 8 : k == 1 ? 10 : 12);
+    const bool all8 = reserve > 0 ? comm_agree_all(h, fits8) : true;
+    if (reserve > 0 && (reserve > 1 || !all8) && comm_agree_all(h, fits_reserved)) {
+      comm_reserve_cus(h);  // (a rank that cannot stays on its plain stream with the 8-entry limit: the agreement below then says "two passes" for all)
+      if (h->cu_reserved) {  // choose the instantiation again, with the masked stream's limits
+        per_thread_max = 12;
+        nwg = 1, per_thread = 1 << 30, e_inst = 0;
+        for (int k = 0; k < 3; ++k) {
+          const int es[3] = {8, 10, 12};
+          const int cap = h->mgs_dist_cap_reserved[k];
+          if (cap <= 0) continue;
+          nwg = std::max(1, std::min(cap, cdiv(n, 256 * 4)));
+          per_thread = cdiv(n, (int64_t)nwg * 256);
+          e_inst = es[k];
+          if (per_thread <= es[k]) break;
+        }
+      }
+    }
+  }
   if (dist) {
     // does the resident grid hold the vector -- on EVERY rank?  (local lengths differ; a rank on the two-pass sweep and a rank on the
     // persistent one would all-reduce differently laid-out buffers.)  Agreed once per vector length = per role of the solve.

@@ -191,6 +191,64 @@ void comm_prepare_streams(nsx_handle *h) {
   ensure_comm_stream(h);
   if (getenv("NSX_DEBUG")) fprintf(stderr, "[nsx] communication stream runs beside a waiting compute kernel: %d\n", h->comm_probe_local);
 }
+// A persistent grid whose waves allocate 256 VGPRs leaves RCCL's generic kernel (264 per lane) no place on any CU it touches, and the
+// dispatcher touches them all.  A compute stream with a CU mask does: bit i of the mask is CU i / 8 of XCD i % 8
+// (profiles/r04_cu_mask_bits.txt, tools/cu_mask_probe.hip), RCCL's workgroup k goes to XCD k % 8, so clearing bits 0..7 keeps one CU
+// of every XCD out of the compute stream's reach -- 3 % of the device -- and the communication stream (no mask) finds it free.  From
+// then on h->stream is the masked stream; the plain one is kept until the handle goes.  (A grid on the masked stream is co-resident up
+// to 2 x 7 workgroups per shader engine, 448 in all: the workgroups of an XCD are dealt to its four shader engines in turn, and the
+// one that lost a CU holds 14 -- profiles/r04_cu_mask_residency.txt.)
+bool comm_reserve_cus(nsx_handle *h) {
+  if (h->cu_reserved) return true;
+  int cus = 0;
+  HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->prm.device));
+  if (cus < 64 || cus % 8) return false;
+  std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0xffffffffu);
+  if (cus % 32) mask.back() = (1u << (cus % 32)) - 1u;
+  mask[0] &= ~0xffu;
+  hipStream_t masked = nullptr;
+  if (hipExtStreamCreateWithCUMask(&masked, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  HIP_CHECK(hipStreamSynchronize(h->stream));
+  hipStream_t plain = h->stream;
+  h->stream = masked;
+  // The communication stream gets the complementary mask -- the eight reserved CUs and nothing else: an unmasked stream's workgroup is
+  // dealt to ONE shader engine of its XCD whatever is free there, and three of the four are full while the grid waits (a one-thread
+  // release kernel sat in such a queue until the grid gave up).  It must not share a hardware queue with the compute stream either.
+  auto drop_comm_stream = [&] {
+    if (h->ev_ready) (void)hipEventDestroy(h->ev_ready);
+    h->ev_ready = nullptr;
+    if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
+    h->comm_stream = nullptr;
+  };
+  std::vector<uint32_t> cmask(mask.size(), 0u);
+  cmask[0] = 0xffu;
+  bool ok = false;
+  for (int attempt = 0; attempt < 6 && !ok; ++attempt) {
+    drop_comm_stream();
+    if (hipExtStreamCreateWithCUMask(&h->comm_stream, (uint32_t)cmask.size(), cmask.data()) != hipSuccess) {
+      (void)hipGetLastError();
+      h->comm_stream = nullptr;
+      break;
+    }
+    HIP_CHECK(hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
+    ok = probe_streams_local(h);
+  }
+  if (!ok) {
+    drop_comm_stream();
+    h->stream = plain;
+    (void)hipStreamDestroy(masked);
+    ensure_comm_stream(h);
+    h->comm_probe_local = probe_streams_local(h) ? 1 : 0;
+    return false;
+  }
+  h->stream_plain = plain;
+  h->cu_reserved = 8;
+  if (getenv("NSX_DEBUG")) fprintf(stderr, "[nsx] compute stream replaced by one that leaves one CU per XCD to the communication stream\n");
+  return true;
+}
 // ... on every rank?  The ranks take the minimum of their answers (one collective in the lifetime of a handle), so that all of them
 // use the collective-inside-the-grid sweep or none does.
 bool comm_streams_concurrent(nsx_handle *h) {

@@ -309,6 +309,9 @@ struct nsx_handle {
   std::map<int, int> mgs_dist_fit;   // local vector length -> do ALL ranks' resident grids hold their vector of this role (agreed once per length)
   int cgd_agreed = -1;               // two-launch Schur CG: -1 not decided for the current schedules, 0 / 1 the ranks' common answer
   nsx::DevBuf<double> ext_self;           // development (NSX_EXT_SELF_P2P): operands of the self-addressed send / receive in front of the sweep's collective
+  hipStream_t stream_plain = nullptr;  // the compute stream of the handle's creation once `stream` has been replaced by one with a CU mask (comm_reserve_cus)
+  int cu_reserved = 0;               // CUs (one per XCD) the compute stream leaves to the communication stream's kernels
+  int mgs_dist_cap_reserved[3] = {0, 0, 0};  // grid limits of the distributed sweep's instantiations on the masked compute stream
   int comm_probe_local = -1;         // -1 not probed, 0 / 1: kernels of the communication stream run beside a waiting kernel of the compute stream (comm_prepare_streams)
   int mgs_dist_state = -1;           // -1 not decided yet, 0 two-pass sweep (mgs_lowsync), 1 the collective inside the persistent grid
   int mgs_max_wg_dist[3] = {0, 0, 0};  // resident-grid limits of the distributed instantiations (8 / 10 / 12 entries per thread), room left for the collective
@@ -475,6 +478,7 @@ void solve_time_step(nsx_handle *h, int type, double tol, double inner_rtol, int
 void comm_allreduce_scalars(nsx_handle *h, int slot0, int count);
 void comm_allreduce_partials(nsx_handle *h, double *partials, int count);  // in place, same count on every rank
 bool comm_agree_all(nsx_handle *h, bool mine);  // true iff `mine` is true on every rank (one collective): path choices that change the collective sequence
+bool comm_reserve_cus(nsx_handle *h);  // replace the compute stream by one whose CU mask leaves one CU per XCD free (RCCL's kernel beside a persistent grid)
 bool comm_streams_concurrent(nsx_handle *h);  // probe + agreement of all ranks (one collective): may a compute kernel wait for the communication stream?
 bool comm_on_stream(const nsx_handle *h);  // RCCL backend: collectives are stream operations (the callback backend runs them on the host)
 // the collective inside a persistent grid's exchange: on the communication stream wait for `arrive` to reach `expected`, all-reduce

@@ -593,6 +593,7 @@ int nsx_destroy(nsx_handle *h) {
   if (h->scal_host) (void)hipHostFree(h->scal_host);
   if (h->pub_host) (void)hipHostFree(h->pub_host);
   if (h->stream) (void)hipStreamDestroy(h->stream);
+  if (h->stream_plain) (void)hipStreamDestroy(h->stream_plain);
   delete h;
   return NSX_OK;
 }

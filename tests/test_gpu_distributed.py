@@ -216,3 +216,39 @@ def test_time_out_of_the_sweep_with_the_collective_inside_falls_back_on_every_ra
     assert np.abs(x0 - x1).max() < 1e-9 * np.abs(x0).max()
     assert p1["fallbacks"] >= 1 and not p1["sweep_persistent"]
     assert t1.get("mgs_sweep", {}).get("launches", 0) >= 1 and t1.get("mgs_dots", {}).get("launches", 0) > 0   # one failed launch, two passes from then on
+
+
+def test_masked_streams_keep_the_collective_inside_the_larger_grids():
+    """Above 917 k entries per GPU the sweep needs the 10- / 12-entry instantiations, which leave RCCL's kernel (264 VGPRs) no room on
+    any CU they touch: the compute stream is then replaced by one whose CU mask leaves one CU per XCD out, and the communication
+    stream confined to those eight (comm_reserve_cus).  NSX_COMM_CU_RESERVE=2 forces that on a small mesh, NSX_EXT_SELF_P2P=1 puts a
+    real RCCL kernel (a self-addressed send / receive) in front of every collective of the sweep: persistent sweep, no time-out, the
+    two-pass sweep's history and solution."""
+    from navierstokes_project_nm4pde_amd import nsx
+    from navierstokes_project_nm4pde_amd.frontend import DoFs, Mesh, Tables
+    from navierstokes_project_nm4pde_amd.problem import InletVelocity, cylinder_boundary_values
+    mesh = Mesh.cylinder(3, 2).partition(1, 8)
+    dofs, tables = DoFs(mesh, "colour"), Tables(3)
+    out = []
+    for env in ({"NSX_MGS_DIST": "0"}, {"NSX_COMM_CU_RESERVE": "2", "NSX_EXT_SELF_P2P": "1"}):
+        os.environ.update(env)
+        try:
+            dev = nsx.Nsx(dofs, tables, 1e-3, 2e-4)
+            dev.comm_init_single()
+            dev.set_solution(np.zeros(dofs.n_dofs))
+            dev.assemble(nsx.TEMAM)
+            dev.apply_boundary_values(*cylinder_boundary_values(dofs, InletVelocity(3), 2e-4))
+            dev.profile(True)
+            st = dev.solve_time_step(nsx.ASIMPLE, tol_abs=1e-10, inner_rtol=1e-8)
+            out.append((st, dev.solution_owned.copy(), dev.profile_table(), dev.persistent_state()))
+            dev.close()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    (s0, x0, t0, p0), (s1, x1, t1, p1) = out
+    assert s0["status"] == 0 and s1["status"] == 0
+    for key in ("outer_iterations", "inner_F_iterations", "inner_S_iterations"):
+        assert abs(s0[key] - s1[key]) <= max(1, 0.02 * s0[key]), key
+    assert np.abs(x0 - x1).max() < 1e-9 * np.abs(x0).max()
+    assert p1["fallbacks"] == 0 and p1["sweep_persistent"] and p1["dirty_mailbox_words"] == 0
+    assert t1.get("mgs_sweep", {}).get("launches", 0) > 0 and t1.get("mgs_dots", {}).get("launches", 0) == 0
