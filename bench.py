@@ -47,7 +47,11 @@ BASE_LEVEL, BASE_DOFS = 7, 1089643  # the N = 1 workload: level-7 cylinder mesh
 BIG_LEVEL, BIG_DOFS = 16, 10644763  # the "~10 M DoF" mesh of BASELINE.json configs[3] (level 14 has 7.3 M)
 if os.environ.get("NSX_BENCH_BIG_LEVEL"):  # development only: rehearse the strong_10M leg's control flow on a small mesh
     BIG_LEVEL, BIG_DOFS = int(os.environ["NSX_BENCH_BIG_LEVEL"]), None
-BIG_STEPS, BIG_WARMUP, BIG_SPINUP = 6, 1, 3  # schedule of the strong_10M leg: the same on one GPU (committed base) and on N (short: at N = 2 a step of
+if os.environ.get("NSX_BENCH_BIG_SCHEDULE"):  # development only (one-card rehearsals): "steps,warmup,spinup" of the strong_10M leg; the line says what ran
+    _BIG_SCHEDULE = tuple(int(v) for v in os.environ["NSX_BENCH_BIG_SCHEDULE"].split(","))
+else:
+    _BIG_SCHEDULE = None
+BIG_STEPS, BIG_WARMUP, BIG_SPINUP = _BIG_SCHEDULE or (6, 1, 3)  # schedule of the strong_10M leg: the same on one GPU (committed base) and on N (short: at N = 2 a step of
                                              # this mesh still takes seconds, and the whole invocation has to stay within minutes)
 PMC_PROFILE = "profiles/r04_pmc_fetch_write_per_kernel.json"
 LAYOUT_PROFILE = "profiles/r04_layout_iterations.json"
@@ -222,23 +226,28 @@ def beat(msg, every=30.0):
 
 
 def gpu_run(dofs, tables, steps, warmup, schur_blocks, device, profile_steps=5, barrier=None, rank=0, world=1, want_state=False, spinup=0,
-            layout=None, comm_single=False, cache_off_twin=False):
-    """first step + `spinup` steps (state preparation) + warmup + `steps` timed steps (+ the same timed steps once more with the
-    reference's own schedule of the preconditioner set-up, + a separate per-kernel HIP-event pass).  The handle is closed on every
-    path: a failure must not leave a communicator or a second copy of the problem behind."""
+            layout=None, comm_single=False, hoisted_twin=False):
+    """first step + `spinup` steps (state preparation) + warmup + `steps` timed steps with the REFERENCE's schedule of the
+    preconditioner set-up (Schur product, ILU(S) and block inverses rebuilt in every step, Preconditioners.hpp:358-362: NSX_SCHUR_CACHE=0
+    unless the environment says otherwise; a handle with a communicator rebuilds anyway) (+ the same timed steps once more with those
+    products kept while their inputs are bit-identical, + a separate per-kernel HIP-event pass).  The handle is closed on every path: a
+    failure must not leave a communicator or a second copy of the problem behind."""
     import numpy as np
     from navierstokes_project_nm4pde_amd import nsx
     from navierstokes_project_nm4pde_amd.problem import InletVelocity, cylinder_boundary_values
     # NSX_BENCH_COMM=callbacks (development only): host-callback exchange over torch.distributed instead of RCCL, which lets
     # the N > 1 control flow be rehearsed with several ranks on ONE card
     t_setup = time.perf_counter()
+    cache_env = os.environ.get("NSX_SCHUR_CACHE")
+    if cache_env is None:
+        os.environ["NSX_SCHUR_CACHE"] = "0"   # read by the library at every preconditioner initialisation
     beat("%d DoF: handing the mesh over (set-up products, internal layout)" % dofs.n_dofs, every=0.0 if dofs.n_dofs > 3e6 else 30.0)
     dev = nsx.Nsx(dofs, tables, NU, DT, device=device, rank=rank, world=world, comm=os.environ.get("NSX_BENCH_COMM", "rccl"), layout=layout)
     try:
         if not layout and schur_blocks < dofs.n_subdomains:
             dev.set_schur_blocks(schur_block_table(dofs, schur_blocks, rank, world))
         if comm_single:
-            dev.comm_init_single()  # 1-rank RCCL communicator: every reduction becomes a launch + ncclAllReduce, the persistent kernels are off
+            dev.comm_init_single()  # 1-rank RCCL communicator: every reduction becomes a launch + ncclAllReduce, the sweep keeps its collective inside, the Schur CG takes two launches per iteration
         inlet = InletVelocity(3)  # test case 2, u_m = 9 (reference NavierStokes3D.hpp:37,80)
         dev.set_solution(np.zeros(dofs.n_dofs))  # u_0 = 0 (reference NavierStokes3D.hpp:200)
         t = 0.0
@@ -261,7 +270,7 @@ def gpu_run(dofs, tables, steps, warmup, schur_blocks, device, profile_steps=5, 
         t_setup = time.perf_counter() - t_setup
         for _ in range(spinup + warmup):
             one_step(False)
-        twin_state = (dev.solution_owned, t) if (cache_off_twin and world == 1) else None
+        twin_state = (dev.solution_owned, t) if (hoisted_twin and world == 1 and not comm_single and cache_env is None) else None
         if barrier:
             barrier()
         c0 = dev.comm_counters() if (world > 1 or comm_single) else (0, 0)
@@ -274,30 +283,34 @@ def gpu_run(dofs, tables, steps, warmup, schur_blocks, device, profile_steps=5, 
         if stats:
             stats[0]["setup_and_first_step_s"] = t_setup
             stats[0]["layout"] = dev.layout_info()
+            stats[0]["paths"] = dev.path_info()
+            if world > 1:  # every rank says which paths it took / would take under RCCL (a rehearsal over host callbacks runs the two-pass sweep)
+                print("bench.py: rank %d of %d, %d DoF: paths %s" % (rank, world, dofs.n_dofs, json.dumps(stats[0]["paths"])), file=sys.stderr, flush=True)
+            stats[0]["schur_cache"] = os.environ.get("NSX_SCHUR_CACHE") != "0" and world == 1 and not comm_single
         if (world > 1 or comm_single) and stats:  # collectives this rank issued per timed step (nsx_comm_counters)
             c1 = dev.comm_counters()
             stats[0]["allreduces_per_step"] = (c1[0] - c0[0]) / float(steps)
             stats[0]["ghost_exchanges_per_step"] = (c1[1] - c0[1]) / float(steps)
         state = (dev.gather_solution() if world > 1 else dev.solution_owned, t) if want_state else None
         if twin_state is not None and stats:
-            # the reference's own schedule of the preconditioner set-up -- Schur product + ILU(S) + block inverses rebuilt in EVERY step
-            # (Preconditioners.hpp:358-362) -- on the SAME timed steps: the state in front of the timed region is restored and the steps
-            # are run again with the cache off (all sums are fixed-order, so they walk through the same iteration counts)
+            # the hoisted twin on the SAME timed steps: the state in front of the timed region is restored and the steps are run again
+            # with the Schur product, its ILU(0) factors and the block inverses kept while their inputs are bit for bit unchanged
+            # (Yosida: always) -- all sums are fixed-order, so they walk through the same iteration counts
             t_end = t
             dev.set_solution(twin_state[0])
             t = twin_state[1]
-            os.environ["NSX_SCHUR_CACHE"] = "0"
+            os.environ["NSX_SCHUR_CACHE"] = "1"
             try:
                 torch_sync = barrier or (lambda: None)
                 torch_sync()
                 t0 = time.perf_counter()
-                off = [one_step(False) for _ in range(steps)]
+                kept = [one_step(False) for _ in range(steps)]
                 torch_sync()
-                el_off = time.perf_counter() - t0
+                el_kept = time.perf_counter() - t0
             finally:
-                os.environ.pop("NSX_SCHUR_CACHE", None)
-            stats[0]["cache_off"] = {"elapsed": el_off, "t_prec": sum(s["t_prec"] for s in off) / len(off),
-                                     "outer": [s["outer_iterations"] for s in off]}
+                os.environ["NSX_SCHUR_CACHE"] = "0"
+            stats[0]["hoisted"] = {"elapsed": el_kept, "t_prec": sum(s["t_prec"] for s in kept) / len(kept),
+                                   "outer": [s["outer_iterations"] for s in kept]}
             assert abs(t - t_end) < 1e-12
         # per-kernel HIP-event pass (separate from the throughput pass: event pairs perturb the launch stream)
         table, prof_stats = {}, []
@@ -312,6 +325,8 @@ def gpu_run(dofs, tables, steps, warmup, schur_blocks, device, profile_steps=5, 
         return elapsed, stats, table, prof_stats, state
     finally:
         dev.close()
+        if cache_env is None:
+            os.environ.pop("NSX_SCHUR_CACHE", None)
 
 
 def cpu_step_from_state(dofs, tables, x, t_state, threads, compact=False):
@@ -535,8 +550,10 @@ def main():
     ap.add_argument("--balance", choices=("cells", "owned"), default="cells",
                     help="what the front-end's partitioner equalises over the ranks it is asked for: cells (METIS-like) or owned P2 nodes")
     ap.add_argument("--comm", choices=("auto", "rccl1"), default="auto",
-                    help="rccl1 (one GPU): put a 1-rank RCCL communicator on the handle, i.e. time the DISTRIBUTED code path (one launch + one "
-                         "ncclAllReduce per reduction, no persistent kernels) on one card")
+                    help="rccl1 (one GPU): put a 1-rank RCCL communicator on the handle, i.e. time the DISTRIBUTED solver paths on one card (one launch + one "
+                         "ncclAllReduce per reduction, the Gram-Schmidt sweep with the collective inside its persistent grid, the Schur CG in two launches per "
+                         "iteration; no ghost exchange: one rank has no neighbours).  The line also carries the same run with a real RCCL kernel "
+                         "(self-addressed send / receive, NSX_EXT_SELF_P2P=2) in front of every all-reduce")
     ap.add_argument("--no-big", action="store_true", help="N > 1: skip the strong_10M leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-only", action="store_true", help="only the cpu_baseline leg (after a short GPU run that provides its state)")
@@ -617,7 +634,7 @@ def main():
             el, stats, table, prof_stats, state = gpu_run(dofs, tables, steps, warmup, args.schur_blocks, local_rank, profile_steps=profile_steps,
                                                           barrier=barrier, rank=rank, world=world, want_state=want_state, spinup=spinup,
                                                           layout=layout_of(args, dofs, world), comm_single=(args.comm == "rccl1" and world == 1),
-                                                          cache_off_twin=twin)
+                                                          hoisted_twin=twin)
         except Exception as e:  # noqa: BLE001
             print("bench.py: rank %d failed in the partitioned run: %s: %s" % (rank, type(e).__name__, e), file=sys.stderr, flush=True)
             os._exit(3)  # peers may be blocked inside a collective: leave at once and let the launcher end them
@@ -630,6 +647,21 @@ def main():
                                                                      want_state=(world == 1 and not args.no_cpu), twin=(world == 1 and not args.cpu_only and args.level is None))
     value = steps / elapsed
     run_big = world > 1 and args.level is None and not args.no_big
+    self_p2p = None
+    if args.comm == "rccl1" and world == 1 and not args.cpu_only and "NSX_EXT_SELF_P2P" not in os.environ:
+        # a 1-rank ncclAllReduce launches no kernel: the same run once more with a self-addressed ncclSend / ncclRecv pair -- a real launch of
+        # RCCL's device kernel -- in front of EVERY all-reduce, those inside the persistent sweep included (csrc/nsx_comm.hip)
+        os.environ["NSX_EXT_SELF_P2P"] = "2"
+        try:
+            n2 = min(steps, 20)
+            el2, st2, _, _, _, _ = partitioned_run(level, n2, warmup, args.spinup, 0)
+            o2 = sum(s_["outer_iterations"] for s_ in st2)
+            self_p2p = {"what": "the same run with NSX_EXT_SELF_P2P=2: a real RCCL kernel (self-addressed send / receive) in front of every all-reduce",
+                        "steps": n2, "value": n2 / el2, "ms_per_step": 1e3 * el2 / n2, "gmres_outer_iters_per_step": o2 / float(n2),
+                        "ms_per_outer_iteration": 1e3 * el2 / max(1, o2), "allreduces_per_step": st2[0].get("allreduces_per_step"),
+                        "persistent_fallbacks": max(s_.get("persistent_fallbacks", 0) for s_ in st2), "paths": st2[0].get("paths")}
+        finally:
+            os.environ.pop("NSX_EXT_SELF_P2P", None)
 
     def big_leg(on_deadline):
         """strong_10M: the 10 644 763-DoF mesh partitioned over the N GPUs, the schedule of its committed one-GPU base.  The headline of
@@ -642,8 +674,15 @@ def main():
 
         def watchdog():
             if not finished.wait(deadline):
-                on_deadline({"error": failure[0] if failure else "not finished after %.0f s (NSX_BENCH_BIG_DEADLINE)" % deadline, "n_gpus": world})
-                os._exit(0)
+                # the measured headline goes out first (rank 0); the other ranks leave a little later, so that the launcher does not end rank 0
+                # before it has written.  A rank that RAISED inside the leg (an NSX_ERR_HIP from a GPU fault, a refused argument) makes the
+                # job exit with code 4: the run record must show it.  A leg that is merely not finished at the deadline is reported in the
+                # line and leaves with 0.
+                if rank != 0:
+                    time.sleep(5.0)
+                on_deadline({"error": failure[0] if failure else "not finished after %.0f s (NSX_BENCH_BIG_DEADLINE)" % deadline, "n_gpus": world,
+                             "failed": bool(failure)})
+                os._exit(4 if failure else 0)
 
         threading.Thread(target=watchdog, daemon=True).start()
         try:
@@ -719,7 +758,7 @@ def main():
                  ("%d blocks" % args.schur_blocks) if args.schur_blocks else ("consecutive ranks merged up to %d rows per block" % SCHUR_ROWS), args.ordering))
     ms_outer = 1e3 * elapsed / max(1, outer)
     mean_long = long_run_mean_outer()
-    off = stats[0].get("cache_off") if stats else None
+    kept = stats[0].get("hoisted") if stats else None
     out = {
         "metric": "time-steps/sec (assemble_time_step + solve_time_step), 3D flow past a cylinder, P2/P1, Yosida, per-rank ILU(0)",
         "value": value, "unit": "time-steps/s", "n_gpus": world,
@@ -731,7 +770,7 @@ def main():
                    "n_dofs": dofs.n_dofs, "n_cells": dofs.n_cells, "numbering": args.numbering, "ranks_input_per_gpu": args.ranks_input if args.numbering == "first_touch" else None,
                    "internal_layout": lay,
                    "parallelism": (("1 GPU, no communication" if args.comm != "rccl1" else
-                                    "1 GPU with a 1-rank RCCL communicator: the DISTRIBUTED code path (one launch + ncclAllReduce per reduction, no persistent kernels)")
+                                    "1 GPU with a 1-rank RCCL communicator: the DISTRIBUTED solver paths (one launch + ncclAllReduce per reduction, collective inside the persistent sweep, two-launch Schur CG; no ghost exchange)")
                                    if world == 1 else
                                    "ONE mesh partitioned over %d GPUs: %s" % (world, "RCCL ghost exchange (grouped ncclSend/ncclRecv) + ncclAllReduce of the dot products"
                                                                           if os.environ.get("NSX_BENCH_COMM", "rccl") == "rccl" else
@@ -748,12 +787,17 @@ def main():
         "inner_S_iters_per_step": sum(s["inner_S_iterations"] for s in stats) / n,
         "setup_and_first_step_s": stats[0].get("setup_and_first_step_s") if stats else None,
         "t_prec_ms_per_step": 1e3 * sum(s["t_prec"] for s in stats) / n,
-        "schur_cache": True,  # timed steps keep the Schur product / ILU(S) / block inverses while their inputs are bit-identical (Yosida: always)
-        # the like-for-like twin: the SAME timed steps run again from the restored state with the reference's schedule (everything rebuilt in every step)
-        "cache_off": ({"value": steps / off["elapsed"], "ms_per_step": 1e3 * off["elapsed"] / steps, "t_prec_ms_per_step": 1e3 * off["t_prec"],
-                       "same_iteration_history": off["outer"] == [s["outer_iterations"] for s in stats],
-                       "what": "measured: the same %d timed steps from the restored state with NSX_SCHUR_CACHE=0 (Schur product, ILU(S) and block inverses rebuilt in every step, Preconditioners.hpp:358-362)" % steps}
-                      if off else None),
+        # `value` is like for like: the timed steps rebuild the Schur product / ILU(S) / block inverses in every step as the reference does
+        # (Preconditioners.hpp:358-362) unless NSX_SCHUR_CACHE was set from outside
+        "schur_cache": stats[0].get("schur_cache") if stats else None,
+        # the hoisted twin: the SAME timed steps run again from the restored state with those products kept while their inputs are bit-identical (Yosida: always)
+        "value_hoisted": (steps / kept["elapsed"]) if kept else None,
+        "hoisted": ({"value": steps / kept["elapsed"], "ms_per_step": 1e3 * kept["elapsed"] / steps, "t_prec_ms_per_step": 1e3 * kept["t_prec"],
+                     "same_iteration_history": kept["outer"] == [s["outer_iterations"] for s in stats],
+                     "what": "measured: the same %d timed steps from the restored state with NSX_SCHUR_CACHE=1 (Schur product, ILU(S) and block inverses kept across steps: their inputs do not change in time with Yosida)" % steps}
+                    if kept else None),
+        "paths": stats[0].get("paths") if stats else None,
+        "self_p2p": self_p2p,
         "persistent_fallbacks": max(s.get("persistent_fallbacks", 0) for s in stats) if stats else None,
         "persistent_state": stats[0].get("persistent_state") if stats else None,
         "allreduces_per_step": stats[0].get("allreduces_per_step") if stats else None,

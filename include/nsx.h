@@ -208,6 +208,21 @@ int nsx_profile_get(nsx_handle *h, int i, const char **name, int64_t *launches, 
  * not empty in the region the next launch would use (0 on a healthy handle and after a recovered time-out). */
 int nsx_persistent_state(nsx_handle *h, int state[4]);
 
+/* Which code paths this handle's products and solves take -- for tests, and for the log a multi-GPU rehearsal writes per rank:
+ * info[0] 1 = every F->vmult (reference Preconditioners.hpp:382,405; NavierStokes3D.cpp:574) goes through the LDS-staged SpMV,
+ * [1] its chunks, [2] those of them that stage a ghost column (launched behind the ghost exchange; 0 on one GPU),
+ * [3] entries per thread of the LAST Gram-Schmidt sweep that ran as one persistent launch (8 / 10 / 12; 0: none yet, or two passes),
+ * [4] workgroups of its grid, [5] 1 = with the collective inside, [6] the largest instantiation any sweep has used so far,
+ * [7] CUs the compute stream leaves to the communication stream (0 or 8), [8] the last Schur-complement CG: 1 one launch per
+ * operation, 2 one persistent launch, 3 two launches per iteration, [9] Schur ILU blocks, [10] neighbours of the ghost exchange,
+ * [11] owned P2 nodes sent per exchange, [12] ghost P2 nodes, [13] 1 = explicit inverses of the Schur ILU blocks,
+ * [14] 1 = the persistent sweep is switched off or has fallen back, [15] persistent kernels that timed out so far,
+ * [16] / [17] entries per thread of the sweep instantiation an RCCL run WOULD use for the velocity vector on plain / on CU-masked
+ * streams (0: the resident grid does not hold it: two passes), [18] / [19] the same for the block vector, [20] Schur blocks per
+ * entry of a partial-sum array of the two-launch CG (1: no fold launch), [21] the velocity sweep's instantiation on one GPU without a
+ * communicator, [22] / [23] P2 / P1 nodes this handle owns. */
+int nsx_path_info(nsx_handle *h, int info[24]);
+
 /* SolverGMRES' orthogonalisation (deal.II's modified Gram-Schmidt add_and_dot chain inside every solver.solve of the path: reference
  * NavierStokes3D.cpp:574, Preconditioners.hpp:173,273,288,382,405) on the caller's vectors, through the very sweep kernel the solvers
  * use: vectors[m][n] (row k = vector k) -- vector 0 is normalised, vector k is orthogonalised against vectors 0..k-1 and normalised,
@@ -235,6 +250,12 @@ int nsx_comm_init_callbacks(nsx_handle *h, int rank, int world, nsx_allreduce_fn
  * mgs_lowsync; a second one only when the sweep removes more than 99 % of the vector's norm) where the reference pays one per link
  * of the add_and_dot chain. */
 int nsx_comm_counters(const nsx_handle *h, long long counts[2]);
+/* Test hook: the RCCL branch of the ghost exchange (pack kernel, grouped ncclSend / ncclRecv straight into the ghost region -- the
+ * Epetra_Import of every vmult --, event, wait of the compute stream) on a 1-rank communicator whose only neighbour is the rank
+ * itself: ghost node k of a vector of n_own + n_ghost nodes must receive the ncomp values of owned node (7 k + 3) % n_own.
+ * max_err = largest deviation after three exchanges in a row.  (RCCL refuses two ranks on one device: a one-GPU box has no other way
+ * to execute that branch.) */
+int nsx_comm_self_halo_test(nsx_handle *h, int n_own, int n_ghost, int ncomp, double *max_err);
 /* Distributed mesh, replaces nsx_set_mesh for world > 1.  cell_dofs keep the GLOBAL deal.II numbering; gpu_u_ptr /
  * gpu_p_ptr [world+1] are the P2 / P1 node ranges owned by each rank (locally_owned_dofs per block, reference
  * NavierStokes3D.cpp:71-87).  Cells: first the n_cells_layer1 cells that touch an owned P2 node (every owned row is

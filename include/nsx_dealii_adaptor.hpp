@@ -60,6 +60,7 @@
 #include <nsx.h>
 
 #include <algorithm>
+#include <iostream>
 #include <map>
 #include <set>
 #include <stdexcept>
@@ -154,6 +155,17 @@ public:
       pcout << "nsx: persistent kernels: sweep " << st[0] << ", Schur CG " << st[1] << ", time-outs " << st[2]
             << " -- running on the launch-per-operation path" << std::endl;
     return st[2];
+  }
+
+  // Which paths this rank's handle takes (nsx_path_info): every F->vmult through the LDS-staged SpMV (with MPI: the chunks without a
+  // ghost column while the Epetra_Import-equivalent exchange is in flight, the others behind it), the Schur CG's variant (1 one launch
+  // per operation, 2 one persistent launch, 3 two launches per iteration), neighbours and ghost nodes.  One line per rank.
+  void report_paths(std::ostream &out) const {
+    int p[24];
+    ck(h, nsx_path_info(h, p));
+    out << "nsx rank " << rank << ": LDS-staged SpMV " << p[0] << " (" << p[1] << " chunks, " << p[2] << " behind the ghost exchange), sweep " << p[3]
+        << " entries per thread on " << p[4] << " workgroups, Schur CG path " << p[8] << " on " << p[9] << " blocks, " << p[10] << " neighbours, " << p[12]
+        << " ghost nodes" << std::endl;
   }
 
   // ---- the three members -------------------------------------------------------------------------------------------

@@ -670,12 +670,17 @@ static_assert((size_t)MGS_ONE_VALS * MGS_MAX_WG + MGS_ONE_VALS <= MGS_BLK_REGION
 // release at agent scope makes the compiler invalidate / write back the XCD's whole L2 around the access -- polled by 448 workgroups
 // that doubled the time of the sweep's first phase: profiles/r04_ext_collective_timeline.txt.)
 // ext.vals[MGS_EXT_FAIL], the collective SUMS that word, and a non-zero sum makes every rank's grid end without touching w; the
-// hosts then all redo the sweep with the two-pass path.  The wait for the flag is bounded far above the other time-outs (a rank
-// that fails locally needs two of them before its collective goes out).  When the Gram formula for |w'|^2 is refused (the sweep
+// hosts then all redo the sweep with the two-pass path.  The wait for the flag is bounded ABOVE the other time-outs (mailboxes 2 s,
+// k_ext_wait 4 s: a rank that fails locally needs both before its collective goes out): 8 s.  A flag wait that still times out is a
+// verdict of ONE rank -- its peers' grids may have gone on with the global sums -- so it must not change this rank's collective
+// sequence: the host waits for the (late) collective, finishes the sweep from the global sums it delivered (v_mgs: same coefficients,
+// same updates, no further collective) and raises ext.vals[MGS_EXT_LEAVE] in its NEXT sweep; that word is summed like the failure
+// word, and a non-zero sum takes every rank to the two-pass sweep together.  When the Gram formula for |w'|^2 is refused (the sweep
 // removed > 99 % of the norm: decided from the global sums, i.e. alike on every rank) the grid leaves the LOCAL sum of |w'|^2 in
 // ext.norm_out, does not normalise and reports "norm pending": the host all-reduces that word (the second collective).
-constexpr int MGS_EXT_VALS = 64, MGS_EXT_FAIL = 63;
-constexpr unsigned long long GX_EXT_TIMEOUT_TICKS = 100000000ull;  // 1 s at 100 MHz (a small collective takes tens of microseconds; its connections exist before the first sweep)
+constexpr int MGS_EXT_VALS = 64, MGS_EXT_FAIL = 63, MGS_EXT_LEAVE = 62;
+constexpr unsigned long long GX_EXT_TIMEOUT_TICKS = 800000000ull;  // 8 s at 100 MHz: above the mailbox wait (2 s) + k_ext_wait (4 s) a failing peer needs before its collective goes out
+static_assert(GX_EXT_TIMEOUT_TICKS > 3 * GX_TIMEOUT_TICKS, "the flag wait must outlast a peer's mailbox wait + k_ext_wait");
 struct MgsExt {
   double *vals;              // [MGS_EXT_VALS] this sweep's buffer: local totals, then (after the collective) the global ones
   double *vals_other;        // the other buffer: its failure word is cleared for the next sweep
@@ -683,6 +688,7 @@ struct MgsExt {
   unsigned long long *flag;  // sequence number of the last sweep whose collective is complete
   unsigned long long *abort_seq;  // sequence number of the last sweep a workgroup gave up on: the verdict of the WHOLE grid (see the wait)
   double *norm_out;          // local |w'|^2 when the formula is refused
+  int leave;                 // 1: this rank asks all ranks to leave the persistent sweep (an earlier flag wait of its own timed out)
 };
 __device__ __forceinline__ double ext_ld(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void ext_st(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -807,6 +813,7 @@ __global__ __launch_bounds__(256) void k_mgs_one(int n, int split, int gap, doub
       if (threadIdx.x == 0) {
         if (!s_err) ext_st(ext.vals + v, (sh[0][0] + sh[1][0]) + (sh[2][0] + sh[3][0]));
         else ext_st(ext.vals + MGS_EXT_FAIL, 1.0);  // summed over the ranks: everybody learns of it
+        if (v == 0 && ext.leave) ext_st(ext.vals + MGS_EXT_LEAVE, 1.0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(ext.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // counted in either way: the collective must go out
       }
@@ -846,7 +853,7 @@ __global__ __launch_bounds__(256) void k_mgs_one(int n, int split, int gap, doub
     }
     __syncthreads();
     for (int v = threadIdx.x; v < nvals; v += 256) tot[v] = ext_ld(ext.vals + v);
-    if (threadIdx.x == 0 && ext_ld(ext.vals + MGS_EXT_FAIL) != 0.0) s_err = 1;  // some rank's grid was not complete
+    if (threadIdx.x == 0 && (ext_ld(ext.vals + MGS_EXT_FAIL) != 0.0 || ext_ld(ext.vals + MGS_EXT_LEAVE) != 0.0)) s_err = 1;  // some rank's grid was not complete, or a rank asks everybody to leave
   } else {
     for (int v = threadIdx.x; v < nvals; v += 256) {
       tot[v] = gx_wait_value(total + v, &lerr);
@@ -1068,7 +1075,10 @@ static void mgs_setup(nsx_handle *h) {
     h->mgs_max_wg_dist[k] = std::max(0, std::min(MGS_MAX_WG, slots - std::max(32, slots / 8)));
     // on a compute stream that leaves one CU per XCD to the collective's kernel: every shader engine counts as the one that lost a CU
     h->mgs_dist_cap_reserved[k] = std::max(0, std::min(MGS_MAX_WG, per_cu * (cus - 32)));
-    if (getenv("NSX_MGS_MAXWG")) h->mgs_max_wg_dist[k] = std::max(1, std::min(h->mgs_max_wg_dist[k], atoi(getenv("NSX_MGS_MAXWG"))));
+    if (getenv("NSX_MGS_MAXWG")) {  // (tests: a small mesh then needs the instantiations a large one does)
+      h->mgs_max_wg_dist[k] = std::max(1, std::min(h->mgs_max_wg_dist[k], atoi(getenv("NSX_MGS_MAXWG"))));
+      h->mgs_dist_cap_reserved[k] = std::max(1, std::min(h->mgs_dist_cap_reserved[k], atoi(getenv("NSX_MGS_MAXWG"))));
+    }
   }
   h->mgs_ext_vals.alloc(2 * MGS_EXT_VALS);
   h->mgs_ext_vals.zero(h->stream);
@@ -1290,6 +1300,20 @@ static void mgs_lowsync(nsx_handle *h, Span sp, double *w, int dim, double *cons
   if (consider) out[dim + 1] = tmp[dim + 1];
 }
 
+// the all-reduced sums of a persistent sweep (r_j at j, Gram row at dim + j, |w|^2 at 2 dim) in the layout of k_ls_solve
+__global__ void k_ext_to_ls(int dim, const double *__restrict__ ext_vals, double *__restrict__ ls_vals) {
+  const int t = threadIdx.x;  // 64 threads
+  double v = 0.0;
+  if (t < dim) v = ext_vals[t];
+  else if (t >= 32 && t < 32 + dim) v = ext_vals[dim + (t - 32)];
+  else if (t == 63) v = ext_vals[2 * dim];
+  ls_vals[t] = v;
+}
+
+// which vector of the solve a sweep works on: the same answer on every rank, whatever its local sizes (0 velocity, 1 pressure,
+// 2 block vector, 3 anything else) -- the key under which choices made by all ranks together are remembered
+static int mgs_role(const nsx_handle *h, Span sp) { return sp.split < sp.n ? 2 : sp.n == h->n_u ? 0 : sp.n == h->n_p ? 1 : 3; }
+
 // out[0..dim) = h(i), out[dim] = |w|^2 after the sweep.  Returns true when w was also normalised (only if asked to).
 bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int slot0, bool normalize, double *out,
            const std::function<void()> *after_launch, bool consider, double *gram) {
@@ -1302,7 +1326,7 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
   }
   bool dist = h->comm && h->mgs_dist_state == 1 && !h->mgs_disabled && gram;
   if (!h->comm || dist) mgs_setup(h);
-  dist = dist && h->mgs_links == 0 && 2 * dim + 1 < MGS_EXT_FAIL;
+  dist = dist && h->mgs_links == 0 && 2 * dim + 1 < MGS_EXT_LEAVE;
   // entries per thread: the smallest instantiation (8, 10, 20) whose resident grid covers the vector
   int nwg = 1, per_thread = 1 << 30, e_inst = 0;
   const int n_inst = 3;  // the one-exchange sweep keeps a block of basis vectors in registers: 8, 10 or 12 entries per thread
@@ -1323,9 +1347,12 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
     if (per_thread <= es[k]) break;
   }
   int per_thread_max = (dist && !h->cu_reserved) ? 8 : h->mgs_links == 0 ? 12 : 20;
-  if (dist && !h->cu_reserved && h->mgs_dist_fit.find(n) == h->mgs_dist_fit.end()) {
+  const int role = mgs_role(h, sp);
+  if (dist && !h->cu_reserved && !h->cu_reserve_failed && h->mgs_dist_fit.find(role) == h->mgs_dist_fit.end()) {
     // too long for the 8-entry grid somewhere, but not for the larger instantiations on a masked compute stream?  NSX_COMM_CU_RESERVE:
-    // 0 never, 1 (default) when that is what keeps the collective inside the grid, 2 always.  Every rank takes the same steps.
+    // 0 never, 1 (default) when that is what keeps the collective inside the grid, 2 always.  Every condition below is an answer all
+    // ranks gave together, so every rank takes the same steps -- including the outcome of the reservation itself: if it fails anywhere
+    // (no masked stream, the probe) every rank goes back to its plain streams and nobody asks again on this communicator.
     static const int reserve = getenv("NSX_COMM_CU_RESERVE") ? atoi(getenv("NSX_COMM_CU_RESERVE")) : 1;
     const bool fits8 = e_inst != 0 && per_thread <= 8;
     bool fits_reserved = false;
@@ -1334,7 +1361,11 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
                       cdiv(n, (int64_t)std::max(1, std::min(h->mgs_dist_cap_reserved[k], cdiv(n, 256 * 4))) * 256) <= (k == 0 ? 8 : k == 1 ? 10 : 12);
     const bool all8 = reserve > 0 ? comm_agree_all(h, fits8) : true;
     if (reserve > 0 && (reserve > 1 || !all8) && comm_agree_all(h, fits_reserved)) {
-      comm_reserve_cus(h);  // (a rank that cannot stays on its plain stream with the 8-entry limit: the agreement below then says "two passes" for all)
+      const bool mine = comm_reserve_cus(h);
+      if (!comm_agree_all(h, mine)) {
+        if (mine) comm_release_cus(h);
+        h->cu_reserve_failed = true;
+      }
       if (h->cu_reserved) {  // choose the instantiation again, with the masked stream's limits
         per_thread_max = 12;
         nwg = 1, per_thread = 1 << 30, e_inst = 0;
@@ -1352,9 +1383,9 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
   }
   if (dist) {
     // does the resident grid hold the vector -- on EVERY rank?  (local lengths differ; a rank on the two-pass sweep and a rank on the
-    // persistent one would all-reduce differently laid-out buffers.)  Agreed once per vector length = per role of the solve.
-    auto it = h->mgs_dist_fit.find(n);
-    if (it == h->mgs_dist_fit.end()) it = h->mgs_dist_fit.emplace(n, comm_agree_all(h, e_inst != 0 && per_thread <= per_thread_max) ? 1 : 0).first;
+    // persistent one would all-reduce differently laid-out buffers.)  Agreed once per role of the vector in the solve.
+    auto it = h->mgs_dist_fit.find(role);
+    if (it == h->mgs_dist_fit.end()) it = h->mgs_dist_fit.emplace(role, comm_agree_all(h, e_inst != 0 && per_thread <= per_thread_max) ? 1 : 0).first;
     if (!it->second || dim + 2 > MGS_STEPS) dist = false;
   }
   if ((h->comm && !dist) || h->mgs_max_wg == 0 || dim + 2 > MGS_STEPS || per_thread > per_thread_max || (h->mgs_links == 0 && !gram)) {
@@ -1368,6 +1399,11 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
     return false;
   }
   const unsigned long long seq = ++h->pub_seq;
+  double *ext_vals_this = nullptr;  // distributed: the buffer this sweep's collective works on
+  h->mgs_last_e = e_inst;
+  h->mgs_last_nwg = nwg;
+  h->mgs_last_dist = dist ? 1 : 0;
+  h->mgs_max_e_seen = std::max(h->mgs_max_e_seen, e_inst);
   {
     LaunchScope ls(h, "mgs_sweep", 8.0 * n * (dim + 2));
     MgsArgs V;
@@ -1395,14 +1431,16 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
       int reset_words = reset_wg * reset_steps;
       double *gram_ = gram;
       double guard_ = mgs_norm_guard(h);
-      MgsExt ext{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+      MgsExt ext{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
       if (dist) {
+        ext.leave = h->mgs_leave_req ? 1 : 0;
         ext.vals = h->mgs_ext_vals.p + (size_t)h->mgs_ext_parity * MGS_EXT_VALS;
         ext.vals_other = h->mgs_ext_vals.p + (size_t)(1 - h->mgs_ext_parity) * MGS_EXT_VALS;
         ext.flag = h->mgs_ext_words.p;
         ext.arrive = (unsigned int *)(h->mgs_ext_words.p + 1);
         ext.abort_seq = h->mgs_ext_words.p + 2;
         ext.norm_out = h->scal.p + S_LS_NORM;
+        ext_vals_this = ext.vals;
       }
       void *args[] = {&n_, &split, &gap, &w, &V, &dim_, &gram_, &box, &box_next, &reset_words, &sout, &err, &tail, &norm_, &consider_, &pub_vals, &pub_flag, &seq_, &drop_wg, &guard_, &ext};
       HIP_CHECK(hipLaunchKernel(fn, dim3(nwg), dim3(256), args, 0, h->stream));
@@ -1439,12 +1477,67 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
   if (ran_ahead) (*after_launch)();
   wait_published(h, seq);
   if (*(volatile int *)(h->pub_host + N_SLOTS + 2)) {
+    if (dist) {
+      // Whose verdict was it?  Wait for the collective (the grid is gone, so its kernels find room whatever kept them) and look at the
+      // words it summed: a failure or a leave request is known to every rank alike -- all redo the sweep in two passes.  Neither: only
+      // THIS rank's grid gave up on the flag; its peers may be past this sweep already.
+      HIP_CHECK(hipStreamSynchronize(h->stream));
+      HIP_CHECK(hipStreamSynchronize(h->comm_stream));
+      double words[2] = {0.0, 0.0};
+      HIP_CHECK(hipMemcpy(words, ext_vals_this + MGS_EXT_LEAVE, 2 * sizeof(double), hipMemcpyDeviceToHost));
+      if (words[0] == 0.0 && words[1] == 0.0) {
+        const size_t region = std::max(MGS_REGION, MGS_BLK_REGION);
+        std::vector<unsigned long long> tail(MGS_TAIL, 0);
+        HIP_CHECK(hipMemcpy(tail.data(), h->mgs_box.p + 2 * region, MGS_TAIL * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned int committed = 0;
+        for (unsigned long long v : tail) committed += v == seq;
+        if (committed != 0) NSX_THROW(NSX_ERR_HIP, "Gram-Schmidt sweep: %u workgroups had written w when another one gave up on the collective", committed);
+        if (++h->mgs_local_timeouts > 2)
+          NSX_THROW(NSX_ERR_COMM, "Gram-Schmidt sweep: the collective inside the persistent grid did not arrive within %.0f s for the third time on rank %d", 1e-8 * (double)GX_EXT_TIMEOUT_TICKS, h->rank);
+        fprintf(stderr, "[nsx] warning: rank %d: the collective inside the Gram-Schmidt sweep came too late for its grid (%.0f s): this sweep is finished from the sums it delivered, "
+                        "and all ranks are asked to use the two-pass sweep from the next one on\n", h->rank, 1e-8 * (double)GX_EXT_TIMEOUT_TICKS);
+        // mailboxes and error word as a new handle's; the words of the collective protocol (arrival count, flag, abort word) stay: they are cumulative
+        HIP_CHECK(hipMemsetAsync(h->mgs_box.p, 0xff, 2 * region * sizeof(unsigned long long), h->stream));
+        HIP_CHECK(hipMemsetAsync(h->mgs_box.p + 2 * region, 0, MGS_TAIL * sizeof(unsigned long long), h->stream));
+        *(volatile int *)(h->pub_host + N_SLOTS + 2) = 0;
+        h->mgs_used_wg[0] = h->mgs_used_wg[1] = h->mgs_used_steps[0] = h->mgs_used_steps[1] = 0;
+        h->n_persistent_fallbacks++;
+        h->mgs_leave_req = true;
+        // the sweep itself, from the global sums: coefficients and |w'|^2 as every grid computed them (k_ls_solve evaluates the same formula
+        // in another grouping: a decision on its threshold's knife edge could differ from the peers' in the last bit), then the updates
+        if (!h->ls_partial.p) {
+          h->ls_partial.alloc((size_t)LS_VALS * LS_BLOCKS);
+          h->ls_vals.alloc(LS_VALS);
+        }
+        MgsArgs V;
+        for (int i = 0; i < MGS_STEPS; ++i) V.v[i] = i < dim ? vs[i] : nullptr;
+        hipLaunchKernelGGL(k_ext_to_ls, dim3(1), dim3(64), 0, h->stream, dim, ext_vals_this, h->ls_vals.p);
+        hipLaunchKernelGGL(k_ls_solve, dim3(1), dim3(64), 0, h->stream, dim, h->ls_vals.p, gram, h->scal.p + slot0);
+        for (int i = 0; i <= dim + 1; ++i) h->slot_nb[slot0 + i] = 0;
+        const int nb = red_blocks(h, n);
+        hipLaunchKernelGGL(k_ls_update, dim3(nb), dim3(256), 0, h->stream, n, sp.split, sp.gap, w, V, dim, h->scal.p + slot0, red_out(h, S_LS_NORM, nb));
+        h->slot_nb[S_LS_NORM] = nb > 1 ? nb : 0;
+        double tmp[N_TMP_MAX + 2];
+        read_scalars(h, slot0, dim + 2, tmp);
+        if (!(tmp[dim] > mgs_norm_guard(h) * tmp[dim + 1])) {  // the peers' grids refused the formula as well: the sweep's second collective
+          finalize_slots(h, S_LS_NORM, 1);
+          comm_allreduce_scalars(h, S_LS_NORM, 1);
+          tmp[dim] = read_scalar(h, S_LS_NORM);
+        }
+        h->slot_nb[S_LS_NORM] = 0;
+        for (int i = 0; i <= dim; ++i) out[i] = tmp[i];
+        if (consider) out[dim + 1] = tmp[dim + 1];
+        if (ran_ahead) h->mgs_redo_ahead = true;
+        return false;
+      }
+    }
     const unsigned int committed = mgs_recover(h, seq);
     if (committed != 0) NSX_THROW(NSX_ERR_HIP, "Gram-Schmidt sweep: %u workgroups had written w when another one timed out", committed);
     // what after_launch enqueued (the next operator application) used the unfinished w: its result is a temporary that the
     // caller recomputes when told that w was not normalised here
     // (distributed: the failure word travelled through the collective, so every rank is here and redoes the sweep in two passes)
     if (dist) {
+      h->mgs_leave_req = false;
       if (h->ls_mode < 0) h->ls_mode = getenv("NSX_MGS_LOWSYNC") ? atoi(getenv("NSX_MGS_LOWSYNC")) : 2;
       if (h->ls_mode && dim <= 31) mgs_lowsync(h, sp, w, dim, vs, slot0, out, consider, gram);
       else mgs_chain(h, sp, w, dim, vs, slot0, out, consider);
@@ -1675,6 +1768,60 @@ extern "C" int nsx_persistent_state(nsx_handle *h, int state[4]) {
     state[1] = h->cg_box.p != nullptr && !h->cg_disabled && h->cg_max_wg > 0;
     state[2] = h->n_persistent_fallbacks;
     state[3] = nsx::mgs_dirty_words(h) + nsx::cg_dirty_words(h);
+  } catch (const nsx::Error &e) {
+    h->err = e.msg;
+    return e.code;
+  }
+  return NSX_OK;
+}
+
+// Which code paths this handle's products and solves take (tests, bench.py's rehearsal log): see include/nsx.h
+extern "C" int nsx_path_info(nsx_handle *h, int info[24]) {
+  if (!h || !info) return NSX_ERR_ARG;
+  for (int k = 0; k < 24; ++k) info[k] = 0;
+  if (!h->have_mesh) return NSX_OK;
+  try {
+    HIP_CHECK(hipSetDevice(h->prm.device));
+    const nsx::SpmvBlocked &b = h->blkA;
+    info[0] = nsx::blocked_usable(h) ? 1 : 0;
+    info[1] = b.n_chunks;
+    info[2] = b.n_chunks_if;
+    info[3] = h->mgs_last_e;
+    info[4] = h->mgs_last_nwg;
+    info[5] = h->mgs_last_dist;
+    info[6] = h->mgs_max_e_seen;
+    info[7] = h->cu_reserved;
+    info[8] = h->cg_last_path;
+    info[9] = h->schedS.n_blocks;
+    info[10] = (int)h->haloU.nbr.size();
+    info[11] = h->haloU.nbr.empty() ? 0 : h->haloU.send_ptr[h->haloU.nbr.size()];
+    info[12] = h->N2_loc - h->N2;
+    info[13] = h->schedS.dense ? 1 : 0;
+    info[14] = h->mgs_disabled ? 1 : 0;
+    info[15] = h->n_persistent_fallbacks;
+    // what the distributed sweep WOULD run with an RCCL communicator (a rehearsal over host callbacks runs the two-pass sweep): the
+    // instantiation for the velocity and the block vector on plain streams (only the 8-entry grid leaves RCCL's kernel room) and on
+    // masked ones; 0 = the resident grid does not hold the vector
+    if (!h->mgs_disabled) {
+      nsx::mgs_setup(h);
+      auto fit = [&](int n, const int *caps, int n_inst) {
+        for (int k = 0; k < n_inst; ++k) {
+          const int es[3] = {8, 10, 12};
+          if (caps[k] <= 0) continue;
+          const int nwg = std::max(1, std::min(caps[k], nsx::cdiv(n, 256 * 4)));
+          if (nsx::cdiv(n, (int64_t)nwg * 256) <= es[k]) return es[k];
+        }
+        return 0;
+      };
+      info[16] = fit(h->n_u, h->mgs_max_wg_dist, 1);
+      info[17] = fit(h->n_u, h->mgs_dist_cap_reserved, 3);
+      info[18] = fit(h->n_u + h->n_p, h->mgs_max_wg_dist, 1);
+      info[19] = fit(h->n_u + h->n_p, h->mgs_dist_cap_reserved, 3);
+      info[21] = fit(h->n_u, h->mgs_max_wg_e, 3);  // one GPU, no communicator
+    }
+    info[20] = nsx::cdiv(std::max(1, h->schedS.n_blocks), 1024);  // Schur blocks per entry of a partial-sum array of the two-launch CG (1: no fold launch)
+    info[22] = h->N2;
+    info[23] = h->NP;
   } catch (const nsx::Error &e) {
     h->err = e.msg;
     return e.code;

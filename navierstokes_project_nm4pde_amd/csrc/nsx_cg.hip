@@ -592,6 +592,7 @@ bool cg_schur_persistent(nsx_handle *h, double *x, const double *b, double rtol,
     h->cg_lds_resident = lres;
   }
   h->cg_parity ^= 1;
+  h->cg_last_path = 2;
   wait_published(h, seq);
   const int st = (int)h->pub_host[S_CGP + 2];
   if (st == 3) {
@@ -632,7 +633,11 @@ bool cg_schur_persistent(nsx_handle *h, double *x, const double *b, double rtol,
 // the CGD_PARTS numbers in the same fixed order), so the result does not depend on timing -- and differs from the one-GPU kernel's
 // by the rounding of those sums.  The host waits for the residual published by k_cgd_A(it + 1), i.e. the next direction and product
 // are enqueued speculatively (wasted once per solve, by every rank alike: the collective sequences stay matched).
-constexpr int CGD_PARTS = 1024;
+// More than CGD_PARTS Schur blocks on a rank (the 10.6 M-DoF mesh on one GPU has 4 833, on two 2 417): the kernels leave their per-block
+// partial sums in a raw array and a small launch (k_cgd_fold) adds them in groups of ceil(n_blocks / CGD_PARTS) consecutive blocks, in
+// block order, into the CGD_PARTS-entry array everything else works with -- the collective, the consumers and their fixed-order sums
+// stay as they are, whatever the block count (up to CGD_FOLD_MAX per group: 8 192 blocks, ~17 M DoF per GPU).
+constexpr int CGD_PARTS = 1024, CGD_FOLD_MAX = 8;
 enum { CGD_DH = 0, CGD_P0 = CGD_PARTS, CGD_BB = 3 * CGD_PARTS, CGD_P1 = 4 * CGD_PARTS, CGD_TOTAL = 6 * CGD_PARTS };  // P0 | BB contiguous: one collective after the set-up kernel
 
 // fixed-order sum of CGD_PARTS numbers by the 256 threads of the block (every thread gets it); sh: 4 doubles of its own per call site
@@ -646,9 +651,20 @@ __device__ __forceinline__ double cgd_sum(const double *__restrict__ p, double *
 // other ranks' sums afterwards, and would be added again the next time the array goes out.  The last workgroup clears them (n_arrays
 // consecutive arrays of CGD_PARTS entries) in every launch that fills the array.
 __device__ __forceinline__ void cgd_clear_tail(double *arrays, int n_arrays) {
-  if (blockIdx.x != gridDim.x - 1) return;
+  if (blockIdx.x != gridDim.x - 1 || (int)gridDim.x > CGD_PARTS) return;  // (more blocks than entries: the fold kernel writes every entry)
   for (int a = 0; a < n_arrays; ++a)
     for (int q = (int)gridDim.x + (int)threadIdx.x; q < CGD_PARTS; q += CG_THREADS) arrays[(size_t)a * CGD_PARTS + q] = 0.0;
+}
+// dst[a][g] = raw[a][g * grp] + ... + raw[a][g * grp + grp - 1] (block order; groups beyond the last block: 0), a < gridDim.x / 4
+__global__ __launch_bounds__(256) void k_cgd_fold(int nblk, int grp, const double *__restrict__ raw, double *__restrict__ dst) {
+  const int a = blockIdx.x >> 2, g = (blockIdx.x & 3) * 256 + threadIdx.x;
+  const double *r = raw + (size_t)a * nblk;
+  double s_ = 0.0;
+  for (int k = 0; k < grp; ++k) {
+    const int q = g * grp + k;
+    if (q < nblk) s_ += r[q];
+  }
+  dst[(size_t)a * CGD_PARTS + g] = s_;
 }
 __device__ __forceinline__ void cgd_dense_apply(const double *__restrict__ Pb, int nb, const double *gs, double *hs, int tid) {
   const int grp = tid >> 4, lane = tid & 15;
@@ -673,7 +689,7 @@ __global__ __launch_bounds__(CG_THREADS) void k_cgd_init(const int32_t *__restri
                                                    const int32_t *__restrict__ s_ptr, const double *__restrict__ sval, const uint16_t *__restrict__ slidx,
                                                    const int32_t *__restrict__ sinfo, const int64_t *__restrict__ dn_off, const double *__restrict__ P,
                                                    const double *__restrict__ b, const double *__restrict__ x, double *__restrict__ G, double *__restrict__ H,
-                                                   double *__restrict__ parts) {
+                                                   double *__restrict__ out, int ostride) {  // out: parts + CGD_P0 (stride CGD_PARTS), or the raw array in front of k_cgd_fold
   __shared__ double gs[CG_MAXB], hs[CG_MAXB], hvs[CG_MAXB], xst[CG_MAX_UCOLS], sh[3][4];
   const int wg = blockIdx.x, tid = threadIdx.x;
   const int r0 = bptr[wg], nb = bptr[wg + 1] - r0, u0 = u_ptr[wg], nu = u_ptr[wg + 1] - u0;
@@ -700,11 +716,11 @@ __global__ __launch_bounds__(CG_THREADS) void k_cgd_init(const int32_t *__restri
   const double gh = gx_block_sum(own ? gs[tid] * hs[tid] : 0.0, sh[1]);
   const double bb = gx_block_sum(bi * bi, sh[2]);
   if (tid == 0) {
-    parts[CGD_P0 + wg] = gg;
-    parts[CGD_P0 + CGD_PARTS + wg] = gh;
-    parts[CGD_BB + wg] = bb;
+    out[wg] = gg;
+    out[(size_t)ostride + wg] = gh;
+    out[2 * (size_t)ostride + wg] = bb;
   }
-  cgd_clear_tail(parts + CGD_P0, 3);
+  cgd_clear_tail(out, 3);
 }
 
 // the direction of iteration `it` for the nodes a neighbour needs (the communication stream's pack kernel): the owner's expression
@@ -770,13 +786,13 @@ __global__ __launch_bounds__(CG_THREADS) void k_cgd_A(const int32_t *__restrict_
 
 __global__ __launch_bounds__(CG_THREADS) void k_cgd_B(const int32_t *__restrict__ bptr, const int64_t *__restrict__ dn_off, const double *__restrict__ P, int it,
                                                 double *__restrict__ parts, double *__restrict__ x, double *__restrict__ G, double *__restrict__ H,
-                                                const double *__restrict__ Dc, const double *__restrict__ Hv) {
+                                                const double *__restrict__ Dc, const double *__restrict__ Hv, double *__restrict__ out, int ostride) {
   __shared__ double gs[CG_MAXB], hs[CG_MAXB], sh[4][4];
   const int wg = blockIdx.x, tid = threadIdx.x;
   const int r0 = bptr[wg], nb = bptr[wg + 1] - r0;
   const bool own = tid < nb;
   const double *prev = parts + (((it - 1) & 1) ? CGD_P1 : CGD_P0);
-  double *mine = parts + ((it & 1) ? CGD_P1 : CGD_P0);
+  double *mine = out;  // parts + ((it & 1) ? CGD_P1 : CGD_P0) with stride CGD_PARTS, or the raw array in front of k_cgd_fold
   const double dh = cgd_sum(parts + CGD_DH, sh[0]), gh = cgd_sum(prev + CGD_PARTS, sh[1]);
   const double alpha = gh / dh;
   gs[tid] = 0.0;
@@ -795,7 +811,7 @@ __global__ __launch_bounds__(CG_THREADS) void k_cgd_B(const int32_t *__restrict_
   const double ghn = gx_block_sum(own ? gs[tid] * hs[tid] : 0.0, sh[3]);
   if (tid == 0) {
     mine[wg] = gg;
-    mine[CGD_PARTS + wg] = ghn;
+    mine[(size_t)ostride + wg] = ghn;
   }
   cgd_clear_tail(mine, 2);
 }
@@ -803,16 +819,24 @@ __global__ __launch_bounds__(CG_THREADS) void k_cgd_B(const int32_t *__restrict_
 bool cg_schur_fused(nsx_handle *h, double *x, const double *b, double rtol, int maxiter, int *steps, double *last, int *status) {
   const IluSchedule &s = h->schedS;
   const CgPlan &pl = h->cgplan;
-  static const bool wanted = !(getenv("NSX_CG_FUSED") && atoi(getenv("NSX_CG_FUSED")) == 0);
+  const bool wanted = !(getenv("NSX_CG_FUSED") && atoi(getenv("NSX_CG_FUSED")) == 0);  // read per solve: the tests switch it inside one process
   if (!wanted) return false;  // (one GPU: reached when the persistent kernel cannot run -- more Schur blocks than resident workgroups, i.e. beyond ~1.16 M DoF)
   // whether THIS rank's Schur blocks fit the kernels (dense inverses, <= 256 rows, <= 1024 unique columns per block) depends on its
   // own part of the mesh: the ranks agree once per set of schedules, or one of them would run the launch-per-operation solver's
   // collectives against the others' (found by the 2-process test with 6 virtual ranks per GPU: one rank had a 260-row block)
   if (h->cgd_agreed < 0)
-    h->cgd_agreed = comm_agree_all(h, s.dense && s.max_rows <= CG_MAXB && pl.ok && s.n_blocks <= CGD_PARTS && CG_THREADS == 256) ? 1 : 0;
+    h->cgd_agreed = comm_agree_all(h, s.dense && s.max_rows <= CG_MAXB && pl.ok && s.n_blocks <= CGD_PARTS * CGD_FOLD_MAX && CG_THREADS == 256) ? 1 : 0;
   if (!h->cgd_agreed) return false;
-  if (!pl.values_current) NSX_THROW(NSX_ERR_ARG, "internal: Schur CG before the packed operator values were refreshed");
+  if (!pl.values_current) cg_pack_values(h);  // (as the persistent variant's fall-back to the launch-per-operation solver used to allow: a stale packed copy is refreshed, not an error)
   const int n = h->n_p, len = h->len_p, nblk = s.n_blocks;
+  // more blocks than entries of a partial-sum array: raw sums + fold (see CGD_PARTS)
+  const bool fold = nblk > CGD_PARTS;
+  const int fold_grp = cdiv(nblk, CGD_PARTS);
+  if (fold && (int)h->cgd_raw.n < 3 * nblk) h->cgd_raw.alloc((size_t)3 * nblk);
+  auto fold_into = [&](double *dst, int n_arrays) {
+    if (fold) hipLaunchKernelGGL(k_cgd_fold, dim3(4 * n_arrays), dim3(256), 0, h->stream, nblk, fold_grp, h->cgd_raw.p, dst);
+  };
+  h->cg_last_path = 3;
   if ((int)h->cgd_vec.n < 3 * n + 2 * len) {
     h->cgd_vec.alloc((size_t)3 * n + 2 * len);
     h->cgd_vec.zero(h->stream);
@@ -828,7 +852,8 @@ bool cg_schur_fused(nsx_handle *h, double *x, const double *b, double rtol, int 
   {
     LaunchScope ls(h, "cgd_init", 12.0 * h->gS.nnz() + 8.0 * (double)s.dn_entries + 40.0 * n);
     hipLaunchKernelGGL(k_cgd_init, dim3(nblk), dim3(CG_THREADS), 0, h->stream, s.block_ptr.p, pl.u_ptr.p, pl.u_cols.p, pl.s_ptr.p, pl.s_val.p, pl.s_lidx.p,
-                       pl.s_info.p, s.dn_off.p, s.dn_P.p, b, x, G, H, parts);
+                       pl.s_info.p, s.dn_off.p, s.dn_P.p, b, x, G, H, fold ? h->cgd_raw.p : parts + CGD_P0, fold ? nblk : CGD_PARTS);
+    fold_into(parts + CGD_P0, 3);
   }
   comm_allreduce_partials(h, parts + CGD_P0, 3 * CGD_PARTS);
   int it = 0, conv = 0;
@@ -850,7 +875,8 @@ bool cg_schur_fused(nsx_handle *h, double *x, const double *b, double rtol, int 
     {
       LaunchScope ls(h, "cgd_A", 10.0 * h->gS.nnz() + 40.0 * n);
       hipLaunchKernelGGL(k_cgd_A, dim3(nblk), dim3(CG_THREADS), 0, h->stream, s.block_ptr.p, pl.u_ptr.p, pl.u_cols.p, pl.s_ptr.p, pl.s_val.p, pl.s_lidx.p, pl.s_info.p,
-                         n, nx, parts, H, Dp, Dc, Hv, parts + CGD_DH, pub_vals, pub_flag, seq);
+                         n, nx, parts, H, Dp, Dc, Hv, fold ? h->cgd_raw.p : parts + CGD_DH, pub_vals, pub_flag, seq);
+      fold_into(parts + CGD_DH, 1);
     }
     comm_allreduce_partials(h, parts + CGD_DH, CGD_PARTS);
     wait_published(h, seq);
@@ -861,7 +887,10 @@ bool cg_schur_fused(nsx_handle *h, double *x, const double *b, double rtol, int 
     it = nx;
     {
       LaunchScope ls(h, "cgd_B", 8.0 * (double)s.dn_entries + 56.0 * n);
-      hipLaunchKernelGGL(k_cgd_B, dim3(nblk), dim3(CG_THREADS), 0, h->stream, s.block_ptr.p, s.dn_off.p, s.dn_P.p, it, parts, x, G, H, Dc, Hv);
+      double *mine = parts + ((it & 1) ? CGD_P1 : CGD_P0);
+      hipLaunchKernelGGL(k_cgd_B, dim3(nblk), dim3(CG_THREADS), 0, h->stream, s.block_ptr.p, s.dn_off.p, s.dn_P.p, it, parts, x, G, H, Dc, Hv, fold ? h->cgd_raw.p : mine,
+                         fold ? nblk : CGD_PARTS);
+      fold_into(mine, 2);
     }
     comm_allreduce_partials(h, parts + ((it & 1) ? CGD_P1 : CGD_P0), 2 * CGD_PARTS);
   }

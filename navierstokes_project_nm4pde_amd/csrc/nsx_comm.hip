@@ -11,6 +11,9 @@
 //     N > 1 path be tested on a single GPU.
 #include <rccl/rccl.h>
 
+#include <algorithm>
+#include <cmath>
+
 #include "nsx_grid.hpp"
 
 namespace nsx {
@@ -33,10 +36,7 @@ struct Comm {
 // development (one-GPU boxes, NSX_EXT_SELF_P2P): a self-addressed send / receive pair = a REAL launch of RCCL's generic device kernel on
 // `st` (a 1-rank all-reduce launches none).  1: in front of the collective inside the Gram-Schmidt sweep (communication stream);
 // 2: in front of every all-reduce of the compute stream as well, so that RCCL kernels of ONE communicator alternate between two streams.
-static int self_p2p_mode() {
-  static const int m = getenv("NSX_EXT_SELF_P2P") ? atoi(getenv("NSX_EXT_SELF_P2P")) : 0;
-  return m;
-}
+static int self_p2p_mode(const nsx_handle *h) { return h->self_p2p; }  // read when the communicator is created (nsx_comm_init)
 static void self_p2p(nsx_handle *h, hipStream_t st) {
   Comm *c = h->comm;
   const size_t count = 64;
@@ -56,7 +56,7 @@ void comm_allreduce_scalars(nsx_handle *h, int slot0, int count) {
   if (!c || (c->world == 1 && !c->comm)) return;  // a 1-rank RCCL communicator still runs the collective (API self-test)
   h->n_allreduce++;
   if (c->comm) {
-    if (self_p2p_mode() >= 2) self_p2p(h, h->stream);
+    if (self_p2p_mode(h) >= 2) self_p2p(h, h->stream);
     NCCL_CHECK(ncclAllReduce(h->scal.p + slot0, h->scal.p + slot0, count, ncclDouble, ncclSum, c->comm, h->stream));
   } else {
     HIP_CHECK(hipMemcpyAsync(h->scal_host + slot0, h->scal.p + slot0, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -72,7 +72,7 @@ void comm_allreduce_partials(nsx_handle *h, double *partials, int count) {
   if (!c || (c->world == 1 && !c->comm)) return;
   h->n_allreduce++;
   if (c->comm) {
-    if (self_p2p_mode() >= 2) self_p2p(h, h->stream);
+    if (self_p2p_mode(h) >= 2) self_p2p(h, h->stream);
     NCCL_CHECK(ncclAllReduce(partials, partials, count, ncclDouble, ncclSum, c->comm, h->stream));
   } else {
     c->stage.resize((size_t)count);
@@ -141,6 +141,13 @@ static void ensure_comm_stream(nsx_handle *h) {
   const int prio = getenv("NSX_COMM_PRIO") ? atoi(getenv("NSX_COMM_PRIO")) : 0;  // 1 highest, 0 default, -1 lowest
   HIP_CHECK(hipStreamCreateWithPriority(&h->comm_stream, hipStreamNonBlocking, prio > 0 ? hi : prio < 0 ? lo : (lo + hi) / 2));
   HIP_CHECK(hipEventCreateWithFlags(&h->ev_ready, hipEventDisableTiming));
+}
+
+// A stream that RCCL has launched on must outlive the communicator: RCCL orders the operations of one communicator across the user's
+// streams through events it records on the stream of the PREVIOUS operation, and looks at that stream again when the communicator is
+// destroyed.  Streams the handle no longer uses are parked here and destroyed behind ncclCommDestroy (comm_destroy).
+static void retire_stream(nsx_handle *h, hipStream_t s) {
+  if (s) h->retired_streams.push_back(s);
 }
 
 __global__ void k_probe_wait(const unsigned long long *flag, int *seen) {
@@ -220,7 +227,7 @@ bool comm_reserve_cus(nsx_handle *h) {
   auto drop_comm_stream = [&] {
     if (h->ev_ready) (void)hipEventDestroy(h->ev_ready);
     h->ev_ready = nullptr;
-    if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
+    retire_stream(h, h->comm_stream);
     h->comm_stream = nullptr;
   };
   std::vector<uint32_t> cmask(mask.size(), 0u);
@@ -239,7 +246,7 @@ bool comm_reserve_cus(nsx_handle *h) {
   if (!ok) {
     drop_comm_stream();
     h->stream = plain;
-    (void)hipStreamDestroy(masked);
+    (void)hipStreamDestroy(masked);  // (nothing of RCCL has run on it yet)
     ensure_comm_stream(h);
     h->comm_probe_local = probe_streams_local(h) ? 1 : 0;
     return false;
@@ -248,6 +255,23 @@ bool comm_reserve_cus(nsx_handle *h) {
   h->cu_reserved = 8;
   if (getenv("NSX_DEBUG")) fprintf(stderr, "[nsx] compute stream replaced by one that leaves one CU per XCD to the communication stream\n");
   return true;
+}
+// The way back: the plain compute stream and an unmasked communication stream, as the handle had them before comm_reserve_cus
+// (a rank whose peers could not reserve; a communicator that goes away -- the next one decides again).
+void comm_release_cus(nsx_handle *h) {
+  if (!h->cu_reserved) return;
+  HIP_CHECK(hipStreamSynchronize(h->stream));
+  if (h->comm_stream) HIP_CHECK(hipStreamSynchronize(h->comm_stream));
+  retire_stream(h, h->stream);
+  h->stream = h->stream_plain;
+  h->stream_plain = nullptr;
+  if (h->ev_ready) (void)hipEventDestroy(h->ev_ready);
+  h->ev_ready = nullptr;
+  retire_stream(h, h->comm_stream);
+  h->comm_stream = nullptr;
+  h->cu_reserved = 0;
+  if (h->comm) comm_prepare_streams(h);
+  if (getenv("NSX_DEBUG")) fprintf(stderr, "[nsx] compute stream back on all CUs\n");
 }
 // ... on every rank?  The ranks take the minimum of their answers (one collective in the lifetime of a handle), so that all of them
 // use the collective-inside-the-grid sweep or none does.
@@ -274,8 +298,13 @@ void comm_ext_allreduce(nsx_handle *h, double *vals, int count, int fail_word, u
   ensure_comm_stream(h);
   h->n_allreduce++;
   hipLaunchKernelGGL(k_ext_wait, dim3(1), dim3(1), 0, h->comm_stream, arrive, expected, vals, fail_word);
-  if (self_p2p_mode() >= 1) self_p2p(h, h->comm_stream);  // development: a real RCCL kernel beside the grid that waits for this collective
+  if (self_p2p_mode(h) >= 1) self_p2p(h, h->comm_stream);  // development: a real RCCL kernel beside the grid that waits for this collective
   NCCL_CHECK(ncclAllReduce(vals, vals, count, ncclDouble, ncclSum, c->comm, h->comm_stream));
+  // fault injection (tests, NSX_EXT_LATE_RELEASE=k): the k-th collective of this kind never tells its grid that it is complete -- what a
+  // collective that arrives after the grid's bounded wait looks like to ONE rank
+  const char *late_env = getenv("NSX_EXT_LATE_RELEASE");  // (read per call: the tests switch it inside one process)
+  const int late = late_env ? atoi(late_env) : 0;
+  if (late > 0 && ++h->n_ext_collectives == late) return;
   hipLaunchKernelGGL(k_ext_release, dim3(1), dim3(1), 0, h->comm_stream, flag, seq);
 }
 
@@ -303,7 +332,7 @@ void comm_halo_begin(nsx_handle *h, HaloPlan &p, double *x, int ncomp,
   Comm *c = h->comm;
   const int nn = (int)p.nbr.size();
   if (nn == 0) return;
-  if (!c || c->world == 1) NSX_THROW(NSX_ERR_COMM, "distributed mesh set but no communicator: call nsx_comm_init* first");
+  if (!c || (c->world == 1 && !p.self_test)) NSX_THROW(NSX_ERR_COMM, "distributed mesh set but no communicator: call nsx_comm_init* first");
   ensure_comm_stream(h);
   if (!p.ev_done) HIP_CHECK(hipEventCreateWithFlags(&p.ev_done, hipEventDisableTiming));
   const int n_send = p.send_ptr[nn];
@@ -368,6 +397,24 @@ void comm_halo(nsx_handle *h, HaloPlan &p, double *x, int ncomp) {
 }
 
 void comm_destroy(nsx_handle *h) {
+  // order: everything enqueued has run -> the communicator goes (RCCL looks at the streams of its last operations) -> the streams go
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
+  if (h->comm) {
+    if (h->comm->comm) (void)ncclCommDestroy(h->comm->comm);
+    delete h->comm;
+    h->comm = nullptr;
+  }
+  // a masked compute stream belongs to the communicator that asked for it: the handle goes back to its plain stream (and every kernel to all CUs)
+  if (h->cu_reserved) {
+    try {
+      comm_release_cus(h);
+    } catch (const Error &) {
+    }
+  }
+  h->cu_reserve_failed = false;
+  h->mgs_leave_req = false;
+  h->mgs_local_timeouts = 0;
   for (HaloPlan *p : {&h->haloU, &h->haloP})
     if (p->ev_done) {
       (void)hipEventDestroy(p->ev_done);
@@ -377,11 +424,9 @@ void comm_destroy(nsx_handle *h) {
   h->ev_ready = nullptr;
   if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
   h->comm_stream = nullptr;
+  for (hipStream_t s_ : h->retired_streams) (void)hipStreamDestroy(s_);
+  h->retired_streams.clear();
   h->comm_probe_local = -1;
-  if (!h->comm) return;
-  if (h->comm->comm) (void)ncclCommDestroy(h->comm->comm);
-  delete h->comm;
-  h->comm = nullptr;
 }
 
 }  // namespace nsx
@@ -407,10 +452,51 @@ int nsx_comm_init(nsx_handle *h, int rank, int world, const uint8_t id[128]) {
     ncclUniqueId u;
     memcpy(&u, id, 128);
     NCCL_CHECK(ncclCommInitRank(&h->comm->comm, world, u, rank));
+    h->self_p2p = getenv("NSX_EXT_SELF_P2P") ? atoi(getenv("NSX_EXT_SELF_P2P")) : 0;
     nsx::comm_prepare_streams(h);
     h->mgs_dist_state = -1;  // a new communicator: the paths the ranks choose together are chosen again
     h->mgs_dist_fit.clear();
     h->cgd_agreed = -1;
+  } catch (const nsx::Error &e) {
+    h->err = e.msg;
+    return e.code;
+  }
+  return NSX_OK;
+}
+
+// Test hook (tests/test_gpu_distributed.py): the RCCL branch of the ghost exchange -- pack kernel, grouped ncclSend / ncclRecv straight
+// into the ghost region, event, wait of the compute stream -- on a 1-rank communicator, i.e. with this rank as its own and only
+// neighbour (RCCL refuses two ranks on one device, so a one-GPU box has no other way to execute that code).  A vector of n_own + n_ghost
+// nodes with ncomp values each; ghost k must receive the values of owned node (7 k + 3) % n_own.  max_err = largest deviation.
+int nsx_comm_self_halo_test(nsx_handle *h, int n_own, int n_ghost, int ncomp, double *max_err) {
+  if (!h || !max_err || n_own < 1 || n_ghost < 1 || ncomp < 1 || ncomp > 3) return NSX_ERR_ARG;
+  try {
+    HIP_CHECK(hipSetDevice(h->prm.device));
+    if (!h->comm || !h->comm->comm || h->comm->world != 1) NSX_THROW(NSX_ERR_ARG, "nsx_comm_self_halo_test needs a 1-rank RCCL communicator (nsx_comm_init)");
+    nsx::HaloPlan p;
+    p.self_test = true;
+    p.n_own = n_own;
+    p.nbr = {0};
+    p.send_ptr = {0, n_ghost};
+    p.recv_ptr = {0, n_ghost};
+    std::vector<int32_t> idx(n_ghost);
+    for (int k = 0; k < n_ghost; ++k) idx[k] = (int32_t)((7ll * k + 3) % n_own);
+    p.send_idx.upload(idx, h->stream);
+    p.sendbuf.alloc((size_t)n_ghost * ncomp);
+    std::vector<double> x((size_t)(n_own + n_ghost) * ncomp, -1.0);
+    for (size_t i = 0; i < (size_t)n_own * ncomp; ++i) x[i] = 0.5 + (double)i;
+    nsx::DevBuf<double> xd;
+    xd.upload(x, h->stream);
+    for (int rep = 0; rep < 3; ++rep) {  // several exchanges in a row: the event and the buffers are reused
+      nsx::comm_halo_begin(h, p, xd.p, ncomp);
+      nsx::comm_halo_finish(h, p, xd.p, ncomp);
+    }
+    xd.download(x.data(), x.size(), h->stream);
+    double e = 0.0;
+    for (int k = 0; k < n_ghost; ++k)
+      for (int c = 0; c < ncomp; ++c) e = std::max(e, std::fabs(x[((size_t)n_own + k) * ncomp + c] - (0.5 + (double)((size_t)idx[k] * ncomp + c))));
+    *max_err = e;
+    if (p.ev_done) (void)hipEventDestroy(p.ev_done);
   } catch (const nsx::Error &e) {
     h->err = e.msg;
     return e.code;

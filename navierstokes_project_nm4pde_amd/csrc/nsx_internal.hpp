@@ -165,6 +165,7 @@ struct HaloPlan {
   int n_own = 0;                            // ghosts start at node n_own
   hipEvent_t ev_done = nullptr;             // recorded on the communication stream when the ghosts of the last exchange are in place
   bool in_flight = false;                   // callback backend: packed and copied out, the host exchange itself still to do
+  bool self_test = false;                   // nsx_comm_self_halo_test: a 1-rank communicator whose only neighbour is the rank itself
 };
 
 // Rows of a distributed operator that can be computed before the halo of its input arrives (all their columns are owned)
@@ -189,6 +190,11 @@ struct SpmvBlocked {
   DevBuf<int32_t> desc;
   int grid = 0;
   std::vector<int32_t> order;  // host copy: chunk of every block, -1 = padding
+  // distributed handles: `desc` holds the chunks whose staged columns are all owned (launched while the ghost exchange is in flight),
+  // `desc_if` those that stage a ghost column (launched behind it); frac_if = their share of the non-zeros
+  DevBuf<int32_t> desc_if;
+  int grid_if = 0, n_chunks_if = 0;
+  double frac_if = 0;
 };
 
 // Persistent Schur-complement CG (nsx_cg.hip): negative_S_tilde as slabs of 256 slots per Schur ILU block, 16-bit columns
@@ -306,16 +312,23 @@ struct nsx_handle {
   nsx::DevBuf<unsigned long long> mgs_ext_words;  // [0] release flag, [1] arrival counter (32 bits used), [2] the sweep the grid gave up on
   unsigned int mgs_ext_expected = 0;
   int mgs_ext_parity = 0;
-  std::map<int, int> mgs_dist_fit;   // local vector length -> do ALL ranks' resident grids hold their vector of this role (agreed once per length)
+  std::map<int, int> mgs_dist_fit;   // role of the vector in the solve (mgs_role) -> do ALL ranks' resident grids hold their vector of that role (agreed once per role)
+  bool cu_reserve_failed = false;    // the ranks tried to mask their streams and one of them could not: all are back on plain streams, nobody asks again
+  bool mgs_leave_req = false;        // a flag wait of this rank's grid timed out on its own: the next sweep asks all ranks to leave the persistent path
+  int mgs_local_timeouts = 0;
+  int mgs_last_e = 0, mgs_last_nwg = 0, mgs_last_dist = 0, mgs_max_e_seen = 0;  // the last persistent sweep: entries per thread, grid, collective inside (nsx_path_info)
   int cgd_agreed = -1;               // two-launch Schur CG: -1 not decided for the current schedules, 0 / 1 the ranks' common answer
   nsx::DevBuf<double> ext_self;           // development (NSX_EXT_SELF_P2P): operands of the self-addressed send / receive in front of the sweep's collective
   hipStream_t stream_plain = nullptr;  // the compute stream of the handle's creation once `stream` has been replaced by one with a CU mask (comm_reserve_cus)
+  std::vector<hipStream_t> retired_streams;  // streams RCCL has launched on and the handle no longer uses: destroyed behind ncclCommDestroy (comm_destroy)
   int cu_reserved = 0;               // CUs (one per XCD) the compute stream leaves to the communication stream's kernels
   int mgs_dist_cap_reserved[3] = {0, 0, 0};  // grid limits of the distributed sweep's instantiations on the masked compute stream
   int comm_probe_local = -1;         // -1 not probed, 0 / 1: kernels of the communication stream run beside a waiting kernel of the compute stream (comm_prepare_streams)
   int mgs_dist_state = -1;           // -1 not decided yet, 0 two-pass sweep (mgs_lowsync), 1 the collective inside the persistent grid
   int mgs_max_wg_dist[3] = {0, 0, 0};  // resident-grid limits of the distributed instantiations (8 / 10 / 12 entries per thread), room left for the collective
   long long n_allreduce = 0, n_halo = 0;  // collectives issued (nsx_comm_counters)
+  int self_p2p = 0;                       // development (NSX_EXT_SELF_P2P, read by nsx_comm_init): self-addressed send / receive pairs in front of collectives
+  int n_ext_collectives = 0;              // collectives inside a persistent grid so far (fault injection: NSX_EXT_LATE_RELEASE)
   bool mgs_redo_ahead = false;         // a sweep fell back to the chain after work depending on its w had been enqueued
   // persistent Schur-complement CG (nsx_cg.hip: k_cg_schur): mailbox regions, work vectors (d double-buffered, h)
   nsx::DevBuf<unsigned long long> cg_box;
@@ -327,6 +340,8 @@ struct nsx_handle {
   bool cg_lds_resident = false;                        // ... and with the operator in LDS
   bool cg_variant_said = false;
   bool cg_disabled = false;
+  nsx::DevBuf<double> cgd_raw;              // ... per-block partial sums of a rank with more Schur blocks than entries of a partial-sum array (k_cgd_fold)
+  int cg_last_path = 0;                     // the last Schur CG: 0 none yet, 1 one launch per operation, 2 one persistent launch, 3 two launches per iteration
   nsx::DevBuf<double> cgd_vec, cgd_parts;   // distributed Schur CG in two launches per iteration (cg_schur_fused): g, h, S d, d (double-buffered, with ghosts); partial sums
   // ---- force evaluation (compute_forces): obstacle faces + face-quadrature tables
   int ff_n = 0, ff_nq = 0;
@@ -385,6 +400,7 @@ void run_assemble(nsx_handle *h, bool first, int flags);
 void run_dirichlet(nsx_handle *h, int n, const int32_t *dofs, const double *vals);
 
 // sparse (nsx_sparse.hip)
+bool blocked_usable(const nsx_handle *h);                                                   // F->vmult goes through the LDS-staged SpMV
 void spmv_F(nsx_handle *h, const double *vals, const double *x, double *y);                 // y_u = A x_u   (dim comps)
 void spmv_saddle(nsx_handle *h, const double *x, double *y);                                // full block vmult
 void spmv_G(nsx_handle *h, const double *xp, double *yu, bool accumulate);                  // y_u (+)= block(0,1) x_p
@@ -478,6 +494,7 @@ void solve_time_step(nsx_handle *h, int type, double tol, double inner_rtol, int
 void comm_allreduce_scalars(nsx_handle *h, int slot0, int count);
 void comm_allreduce_partials(nsx_handle *h, double *partials, int count);  // in place, same count on every rank
 bool comm_agree_all(nsx_handle *h, bool mine);  // true iff `mine` is true on every rank (one collective): path choices that change the collective sequence
+void comm_release_cus(nsx_handle *h);  // back to the plain compute stream and an unmasked communication stream
 bool comm_reserve_cus(nsx_handle *h);  // replace the compute stream by one whose CU mask leaves one CU per XCD free (RCCL's kernel beside a persistent grid)
 bool comm_streams_concurrent(nsx_handle *h);  // probe + agreement of all ranks (one collective): may a compute kernel wait for the communication stream?
 bool comm_on_stream(const nsx_handle *h);  // RCCL backend: collectives are stream operations (the callback backend runs them on the host)

@@ -206,8 +206,10 @@ void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> 
       const int64_t n = bptr[b + 1] - bptr[b];
       off[b + 1] = off[b] + n * n;
     }
+    // (blocks of at most 256 rows -- what the Schur CG kernels take -- cost at most 256 entries per row whatever the mesh size: no limit on their total;
+    // the 10.6 M-DoF mesh on one GPU has 4 833 blocks of <= 96 rows, 42 M entries = 335 MB)
     const int64_t limit = getenv("NSX_DENSE_MAX") ? atoll(getenv("NSX_DENSE_MAX")) : ((int64_t)32 << 20);  // entries (256 MB)
-    if (off[nb] > 0 && off[nb] <= limit && s.max_rows <= 4096) {
+    if (off[nb] > 0 && (off[nb] <= limit || (s.max_rows <= 256 && !getenv("NSX_DENSE_MAX"))) && s.max_rows <= 4096) {
       s.dense = true;
       s.dn_entries = off[nb];
       s.dn_off.upload(off, h->stream);
@@ -259,7 +261,8 @@ void setup_ilu_schedule(nsx_handle *h, const Csr &g, const std::vector<int32_t> 
 }
 
 // chunks = [bounds[c], bounds[c+1])
-void build_blocked(nsx_handle *h, const Csr &g, const std::vector<int32_t> &bounds, SpmvBlocked &b) {
+// n_own: columns below it are owned by this handle (one GPU: all of them)
+void build_blocked(nsx_handle *h, const Csr &g, const std::vector<int32_t> &bounds, SpmvBlocked &b, int n_own) {
   b.n_chunks = (int)bounds.size() - 1;
   std::vector<int32_t> cptr((size_t)b.n_chunks + 1, 0), ucols, tmp;
   std::vector<uint16_t> lidx(g.nnz());
@@ -278,46 +281,64 @@ void build_blocked(nsx_handle *h, const Csr &g, const std::vector<int32_t> &boun
     b.max_ucols = std::max<int>(b.max_ucols, (int)tmp.size());
   }
   b.ucols_total = (double)ucols.size();
-  {
-    // XCD k takes the chunks [cut[k], cut[k+1]): boundaries where the running non-zero count passes k / 8 of the total
-    const int64_t total = g.rowptr[bounds[b.n_chunks]] - g.rowptr[bounds[0]];
+  // launch tables.  One-GPU handles: one table over all chunks.  Distributed handles (n_own < number of columns): the chunks whose
+  // staged columns are all owned go into the first table -- launched while the ghost exchange is in flight -- and the chunks that stage
+  // a ghost column into the second one, launched behind it (the Epetra_Import + local multiply of every vmult, Preconditioners.hpp:382,405).
+  // Same kernel, same lanes, same sums per row as on one GPU.
+  auto make_desc = [&](const std::vector<int32_t> &chunks, DevBuf<int32_t> &out, int &grid, std::vector<int32_t> *order) {
+    // XCD k takes the chunks [cut[k], cut[k+1]) of the list: boundaries where the running non-zero count passes k / 8 of the total
+    const int nc = (int)chunks.size();
+    auto cnnz = [&](int c) { return (int64_t)(g.rowptr[bounds[c + 1]] - g.rowptr[bounds[c]]); };
+    int64_t total = 0;
+    for (int c : chunks) total += cnnz(c);
     int cut[9];
     cut[0] = 0;
-    for (int k = 1, c = 0; k <= 8; ++k) {
-      while (c < b.n_chunks && (int64_t)(g.rowptr[bounds[c + 1]] - g.rowptr[bounds[0]]) * 8 <= total * k) ++c;
-      cut[k] = k == 8 ? b.n_chunks : c;
+    int64_t run = 0;
+    for (int k = 1, j = 0; k <= 8; ++k) {
+      while (j < nc && (run + cnnz(chunks[j])) * 8 <= total * k) run += cnnz(chunks[j++]);
+      cut[k] = k == 8 ? nc : j;
     }
     int per_xcd = 0;
     for (int k = 0; k < 8; ++k) per_xcd = std::max(per_xcd, cut[k + 1] - cut[k]);
-    b.grid = 8 * per_xcd;
-    b.order.assign((size_t)b.grid, -1);
-    std::vector<int32_t> desc((size_t)b.grid * 4, 0), list;
+    grid = 8 * per_xcd;
+    if (order) order->assign((size_t)grid, -1);
+    std::vector<int32_t> desc((size_t)grid * 4, 0), list;
     static const bool largest_first = !(getenv("NSX_SPMV_ORDER") && atoi(getenv("NSX_SPMV_ORDER")) == 0);
     for (int k = 0; k < 8; ++k) {
-      list.resize((size_t)(cut[k + 1] - cut[k]));
-      for (size_t j = 0; j < list.size(); ++j) list[j] = cut[k] + (int)j;
-      if (largest_first)
-        std::stable_sort(list.begin(), list.end(), [&](int32_t a, int32_t c) {
-          return g.rowptr[bounds[a + 1]] - g.rowptr[bounds[a]] > g.rowptr[bounds[c + 1]] - g.rowptr[bounds[c]];
-        });
+      list.assign(chunks.begin() + cut[k], chunks.begin() + cut[k + 1]);
+      if (largest_first) std::stable_sort(list.begin(), list.end(), [&](int32_t a, int32_t c) { return cnnz(a) > cnnz(c); });
       for (size_t j = 0; j < list.size(); ++j) {
         const int blk = (int)j * 8 + k, c = list[j];
-        b.order[blk] = c;
+        if (order) (*order)[blk] = c;
         desc[4 * (size_t)blk + 0] = cptr[c];
         desc[4 * (size_t)blk + 1] = cptr[c + 1] - cptr[c];
         desc[4 * (size_t)blk + 2] = bounds[c];
         desc[4 * (size_t)blk + 3] = bounds[c + 1];
       }
     }
-    b.desc.upload(desc, h->stream);
+    out.upload(desc, h->stream);
+  };
+  {
+    std::vector<int32_t> first, second;
+    int64_t nnz_second = 0;
+    for (int c = 0; c < b.n_chunks; ++c) {
+      const bool ghost = cptr[c + 1] > cptr[c] && ucols[(size_t)cptr[c + 1] - 1] >= n_own;  // the list is sorted: its last entry is the largest column
+      (ghost ? second : first).push_back(c);
+      if (ghost) nnz_second += g.rowptr[bounds[c + 1]] - g.rowptr[bounds[c]];
+    }
+    make_desc(first, b.desc, b.grid, &b.order);
+    b.n_chunks_if = (int)second.size();
+    b.grid_if = 0;
+    b.frac_if = g.nnz() ? (double)nnz_second / (double)g.nnz() : 0.0;
+    if (!second.empty()) make_desc(second, b.desc_if, b.grid_if, nullptr);
   }
   b.crow.upload(bounds, h->stream);
   b.cptr.upload(cptr, h->stream);
   b.ucols.upload(ucols, h->stream);
   b.lidx.upload(lidx, h->stream);
   if (getenv("NSX_DEBUG"))
-    fprintf(stderr, "[nsx] blocked spmv: rows %d chunks %d (max %d rows) unique cols/chunk avg %.0f max %d (nnz/unique %.1f)\n", g.n_rows, b.n_chunks,
-            b.max_rows, b.ucols_total / std::max(1, b.n_chunks), b.max_ucols, (double)g.nnz() / b.ucols_total);
+    fprintf(stderr, "[nsx] blocked spmv: rows %d chunks %d (max %d rows; %d of them stage a ghost column: %.1f %% of the non-zeros) unique cols/chunk avg %.0f max %d (nnz/unique %.1f)\n",
+            g.n_rows, b.n_chunks, b.max_rows, b.n_chunks_if, 100.0 * b.frac_if, b.ucols_total / std::max(1, b.n_chunks), b.max_ucols, (double)g.nnz() / b.ucols_total);
 }
 
 // Chunk boundaries of the LDS-staged SpMV.  With a rank table the chunks are unions of consecutive rank blocks: a rank's rows
@@ -332,6 +353,10 @@ static std::vector<int32_t> spmv_chunks(nsx_handle *h) {
   const std::vector<int32_t> &rk = h->rank_u_h;
   const bool by_rank = !(getenv("NSX_SPMV_BY_RANK") && atoi(getenv("NSX_SPMV_BY_RANK")) == 0) && rk.size() > 2 &&
                        (double)n / (double)(rk.size() - 1) <= target;
+  // ranks larger than a chunk (fewer, larger virtual ranks: --ranks 2048 has ~170 rows per block) are cut into equal parts of at most
+  // `target` rows: a chunk still ends where a subdomain ends
+  const bool split_ranks = !by_rank && !(getenv("NSX_SPMV_BY_RANK") && atoi(getenv("NSX_SPMV_BY_RANK")) == 0) && rk.size() > 2 &&
+                           (double)n / (double)(rk.size() - 1) <= 4.0 * target;
   if (by_rank) {
     int start = 0;
     for (size_t r = 1; r < rk.size(); ++r) {
@@ -342,6 +367,14 @@ static std::vector<int32_t> spmv_chunks(nsx_handle *h) {
       }
     }
     bounds.push_back(n);
+  } else if (split_ranks) {
+    for (size_t r = 0; r + 1 < rk.size(); ++r) {
+      const int rows = rk[r + 1] - rk[r];
+      if (rows <= 0) continue;
+      const int parts = (rows + target - 1) / target;
+      for (int q = 1; q <= parts; ++q) bounds.push_back(rk[r] + (int)((int64_t)rows * q / parts));
+    }
+    if (bounds.back() != n) bounds.push_back(n);
   } else {
     for (int r = 128; r < n; r += 128) bounds.push_back(r);
     bounds.push_back(n);
@@ -408,11 +441,12 @@ static void refresh_rank_products(nsx_handle *h) {
   h->sched_dirty = true;
   h->prec_ready = false;
   h->schur_valid = false;  // the Schur ILU blocks follow the tables
+  h->mgs_dist_fit.clear();  // sizes may have changed: what the ranks agreed on for the old ones is asked again (every rank gets here alike)
 }
 
 void ensure_schedules(nsx_handle *h) {
   if (!h->sched_dirty) return;
-  if (!h->dist) build_blocked(h, h->gA.host, spmv_chunks(h), h->blkA);
+  build_blocked(h, h->gA.host, spmv_chunks(h), h->blkA, h->N2);
   // blocks per wave: enough rows to keep the 64 lanes of the lane-owner stream busy (~680 rows: 8 blocks of ~85 rows measured
   // best at 1 M DoF / 4096 ranks: fewer blocks per wave leave idle slots in the stream, more leave too few waves)
   auto blocks_per_wave = [](int n_rows, size_t n_blocks) { return std::max(1, std::min(64, (int)(680.0 * (double)n_blocks / std::max(1, n_rows) + 0.5))); };

@@ -422,7 +422,8 @@ void prec_vmult(nsx_handle *h, int type, double tol, int maxit, double *dst, con
     int steps = 0, status = 0;
     double last = 0.0;
     if (cg_schur_persistent(h, x, b, tol, maxit, &steps, &last, &status)) return SolveResult{status, steps, last};
-    if (cg_schur_fused(h, x, b, tol, maxit, &steps, &last, &status)) return SolveResult{status, steps, last};  // distributed: two launches per iteration
+    if (cg_schur_fused(h, x, b, tol, maxit, &steps, &last, &status)) return SolveResult{status, steps, last};  // distributed, or too many blocks for a resident grid: two launches per iteration
+    h->cg_last_path = 1;
     return cg(h, Sm, x, b, PS, n_p, len_p, tol * norm2(h, n_p, b), maxit, &PSdot);
   };
 

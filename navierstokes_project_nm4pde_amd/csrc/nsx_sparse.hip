@@ -289,19 +289,26 @@ static void launch_S(nsx_handle *h, const double *x, double *y, const int32_t *r
 // their way (second stream, comm_halo_begin / finish); the rows on the partition interface follow once they have arrived.
 // This is the Epetra_Import + local multiply of every vmult with the import hidden behind the interior rows.
 // y_u = A x_u through the LDS-staged kernel; false if the handle has no chunk table for it
-static bool launch_blocked(nsx_handle *h, const double *vals, const double *x, double *y) {
+bool blocked_usable(const nsx_handle *h) {
   static const bool blocked = !(getenv("NSX_SPMV_BLOCKED") && atoi(getenv("NSX_SPMV_BLOCKED")) == 0);
   const SpmvBlocked &b = h->blkA;
-  if (!blocked || b.n_chunks == 0 || b.max_rows > 448) return false;
+  return blocked && b.n_chunks > 0 && b.max_rows <= 448 && (size_t)b.max_ucols * h->dim * sizeof(double) <= 64 * 1024;
+}
+// part 0: the table of a one-GPU handle / the chunks of a distributed handle whose staged columns are all owned; part 1: the chunks that
+// stage a ghost column (distributed handles only; an empty table launches nothing)
+static bool launch_blocked(nsx_handle *h, const double *vals, const double *x, double *y, int part = 0) {
+  const SpmvBlocked &b = h->blkA;
+  if (!blocked_usable(h)) return false;
   const size_t shm = (size_t)b.max_ucols * h->dim * sizeof(double);
-  if (shm > 64 * 1024) return false;
-  const int grid = b.grid;
+  const int grid = part ? b.grid_if : b.grid;
+  const int32_t *desc = part ? b.desc_if.p : b.desc.p;
+  if (grid == 0) return true;
 #define NSX_BLK(D) \
-  hipLaunchKernelGGL((k_spmv_blocked<D, 16>), dim3(grid), dim3(256), shm, h->stream, h->N2, b.desc.p, h->gA.rowptr.p, b.lidx.p, vals, b.ucols.p, x, y)
+  hipLaunchKernelGGL((k_spmv_blocked<D, 16>), dim3(grid), dim3(256), shm, h->stream, h->N2, desc, h->gA.rowptr.p, b.lidx.p, vals, b.ucols.p, x, y)
 #ifdef NSX_SPMV_TRACE
   static int n_call = 0;
   const bool traced = getenv("NSX_SPMV_TRACE_OUT") && ++n_call == (getenv("NSX_SPMV_TRACE_CALL") ? atoi(getenv("NSX_SPMV_TRACE_CALL")) : 5000);
-  for (int mode = 0; traced && mode <= 4; ++mode) {  // every variant once, traced; the untraced launch below leaves the right y behind
+  for (int mode = 0; traced && part == 0 && mode <= 4; ++mode) {  // every variant once, traced; the untraced launch below leaves the right y behind
     unsigned long long *tr = nullptr;
     (void)hipStreamSynchronize(h->stream);
     (void)hipMalloc(&tr, (size_t)grid * 4 * sizeof(unsigned long long));
@@ -334,14 +341,34 @@ static bool launch_blocked(nsx_handle *h, const double *vals, const double *x, d
   return true;
 }
 
+// algorithmic bytes of a ghost exchange as LaunchScope counts them (pack read + buffer write, both directions)
+static double bytes_halo(const HaloPlan &p, int ncomp) {
+  const int nn = (int)p.nbr.size();
+  return nn ? 16.0 * (p.send_ptr[nn] + p.recv_ptr[nn]) * ncomp : 0.0;
+}
+
 void spmv_F(nsx_handle *h, const double *vals, const double *x, double *y) {
   if (h->dist) {
+    // Scopes: "spmv_F" = the rows that need no ghost (they run while the exchange is in flight), "spmv_F_if" = the rows behind it,
+    // "halo_u_wait" = what the compute stream waits for the exchange once the first launch is through (its exposed part)
     double *xx = const_cast<double *>(x);
-    LaunchScope ls(h, "spmv_F", bytes_vel(h, false));
+    const bool blk = blocked_usable(h);
+    const double frac_if = blk ? h->blkA.frac_if : (double)h->splitA.n_interface / std::max(1, h->N2);
     comm_halo_begin(h, h->haloU, xx, h->dim);
-    launch_vel(h, false, vals, x, nullptr, y, h->splitA.interior.p, h->splitA.n_interior);
-    comm_halo_finish(h, h->haloU, xx, h->dim);
-    launch_vel(h, false, vals, x, nullptr, y, h->splitA.interface.p, h->splitA.n_interface);
+    {
+      LaunchScope ls(h, "spmv_F", bytes_vel(h, false) * (1.0 - frac_if));
+      if (blk) launch_blocked(h, vals, x, y, 0);
+      else launch_vel(h, false, vals, x, nullptr, y, h->splitA.interior.p, h->splitA.n_interior);
+    }
+    {
+      LaunchScope ls(h, "halo_u_wait", bytes_halo(h->haloU, h->dim));
+      comm_halo_finish(h, h->haloU, xx, h->dim);
+    }
+    {
+      LaunchScope ls(h, "spmv_F_if", bytes_vel(h, false) * frac_if);
+      if (blk) launch_blocked(h, vals, x, y, 1);
+      else launch_vel(h, false, vals, x, nullptr, y, h->splitA.interface.p, h->splitA.n_interface);
+    }
     return;
   }
   LaunchScope ls(h, "spmv_F", bytes_vel(h, false));
@@ -382,9 +409,11 @@ void spmv_saddle(nsx_handle *h, const double *x, double *y) {
     comm_halo_begin(h, h->haloU, xx, h->dim);
     comm_halo_begin(h, h->haloP, xx + h->off_p, 1);
   }
+  const bool blk_dist = h->dist && blocked_usable(h);
   {
     LaunchScope ls(h, "spmv_saddle_u", bytes_vel(h, true));
-    if (h->dist) launch_vel(h, true, h->vF.p, x, x + h->off_p, y, h->splitVel.interior.p, h->splitVel.n_interior);
+    if (blk_dist) launch_blocked(h, h->vF.p, x, y, 0);  // F x_u on the chunks without a ghost column; the rest and += block(0,1) x_p behind the exchange
+    else if (h->dist) launch_vel(h, true, h->vF.p, x, x + h->off_p, y, h->splitVel.interior.p, h->splitVel.n_interior);
     else if (launch_blocked(h, h->vF.p, x, y)) launch_G(h, x + h->off_p, y, true, nullptr, h->N2);  // F x_u staged through LDS, then += block(0,1) x_p
     else launch_vel(h, true, h->vF.p, x, x + h->off_p, y, nullptr, h->N2);
   }
@@ -394,9 +423,18 @@ void spmv_saddle(nsx_handle *h, const double *x, double *y) {
     else launch_B(h, x, y + h->off_p, nullptr, h->NP);
   }
   if (h->dist) {
-    comm_halo_finish(h, h->haloU, xx, h->dim);
-    comm_halo_finish(h, h->haloP, xx + h->off_p, 1);
-    launch_vel(h, true, h->vF.p, x, x + h->off_p, y, h->splitVel.interface.p, h->splitVel.n_interface);
+    {
+      LaunchScope ls(h, "halo_up_wait", bytes_halo(h->haloU, h->dim) + bytes_halo(h->haloP, 1));
+      comm_halo_finish(h, h->haloU, xx, h->dim);
+      comm_halo_finish(h, h->haloP, xx + h->off_p, 1);
+    }
+    LaunchScope ls(h, "spmv_saddle_if", 0);
+    if (blk_dist) {
+      launch_blocked(h, h->vF.p, x, y, 1);
+      launch_G(h, x + h->off_p, y, true, nullptr, h->N2);
+    } else {
+      launch_vel(h, true, h->vF.p, x, x + h->off_p, y, h->splitVel.interface.p, h->splitVel.n_interface);
+    }
     launch_B(h, x, y + h->off_p, h->splitB.interface.p, h->splitB.n_interface);
   }
 }

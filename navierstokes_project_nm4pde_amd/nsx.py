@@ -22,7 +22,7 @@ API = [
     "nsx_set_rhs", "nsx_assemble", "nsx_assemble_time_step", "nsx_add_rhs", "nsx_apply_boundary_values",
     "nsx_solve_time_step", "nsx_prec_initialize", "nsx_prec_vmult", "nsx_system_vmult", "nsx_ilu_apply",
     "nsx_export_block", "nsx_schur_nnz", "nsx_schur_get", "nsx_scalar_graph_nnz", "nsx_scalar_graph", "nsx_ilu_get",
-    "nsx_profile_enable", "nsx_profile_reset", "nsx_profile_count", "nsx_profile_get", "nsx_persistent_state", "nsx_comm_unique_id",
+    "nsx_profile_enable", "nsx_profile_reset", "nsx_profile_count", "nsx_profile_get", "nsx_persistent_state", "nsx_path_info", "nsx_comm_self_halo_test", "nsx_comm_unique_id",
     "nsx_comm_init", "nsx_comm_init_callbacks", "nsx_comm_counters", "nsx_set_mesh_distributed", "nsx_set_force_faces", "nsx_compute_forces",
     "nsx_set_internal_layout", "nsx_layout_info", "nsx_layout_get", "nsx_gram_schmidt_cycle",
 ]
@@ -205,11 +205,29 @@ class Nsx:
         self._ck(self.L.nsx_persistent_state(self._h, st))
         return {"sweep_persistent": bool(st[0]), "cg_persistent": bool(st[1]), "fallbacks": int(st[2]), "dirty_mailbox_words": int(st[3])}
 
+    PATH_KEYS = ("spmv_lds_staged", "spmv_chunks", "spmv_chunks_behind_halo", "sweep_entries_per_thread", "sweep_grid", "sweep_collective_inside",
+                 "sweep_entries_per_thread_max", "cus_reserved", "schur_cg_path", "schur_blocks", "neighbours", "nodes_sent_per_exchange", "ghost_nodes",
+                 "schur_dense_inverses", "sweep_off", "fallbacks", "rccl_sweep_velocity_plain", "rccl_sweep_velocity_masked", "rccl_sweep_block_plain",
+                 "rccl_sweep_block_masked", "schur_blocks_per_partial", "sweep_velocity_one_gpu", "owned_p2_nodes", "owned_p1_nodes")
+
+    def path_info(self):
+        """dict: which code paths the handle's products and solves take (nsx_path_info; schur_cg_path: 1 launch per operation,
+        2 persistent, 3 two launches per iteration)"""
+        v = (C.c_int * 24)()
+        self._ck(self.L.nsx_path_info(self._h, v))
+        return {k: int(v[i]) for i, k in enumerate(self.PATH_KEYS)}
+
     def comm_counters(self):
         """(all-reduces, ghost exchanges) issued since the communicator was set"""
         c = (C.c_longlong * 2)()
         self._ck(self.L.nsx_comm_counters(self._h, c))
         return int(c[0]), int(c[1])
+
+    def comm_self_halo_test(self, n_own, n_ghost, ncomp):
+        """largest error of a self-addressed RCCL ghost exchange (nsx_comm_self_halo_test; needs comm_init_single)"""
+        e = C.c_double(0.0)
+        self._ck(self.L.nsx_comm_self_halo_test(self._h, int(n_own), int(n_ghost), int(ncomp), C.byref(e)))
+        return float(e.value)
 
     def comm_init_single(self):
         """1-rank RCCL communicator on this handle: every dot product then goes through ncclAllReduce (API self-test)."""

@@ -67,8 +67,10 @@ def main():
         sols.append(dev.gather_solution())
         forces.append(dev.compute_forces())
     scopes = sorted(k for k, v in dev.profile_table().items() if v["launches"] > 0)
+    info = dev.path_info()
     if rank == 0:
-        np.savez(out_path, sols=np.array(sols), vmult=vm, x=x, u0=u0, iters=np.array(res["iters"]), forces=np.array(forces), scopes=np.array(scopes))
+        np.savez(out_path, sols=np.array(sols), vmult=vm, x=x, u0=u0, iters=np.array(res["iters"]), forces=np.array(forces), scopes=np.array(scopes),
+                 path_keys=np.array(list(info.keys())), path_info=np.array(list(info.values())))
     dev.close()
     dist.destroy_process_group()
 

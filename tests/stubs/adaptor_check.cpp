@@ -28,6 +28,7 @@ struct UsageSketch {
   // the reference's own layout (one ILU(0) block per MPI rank): no internal layout
   void setup_reference_layout() { nsx_.setup(dof_handler, *fe, *quadrature, 1e-3, 2e-4, block_owned_dofs, MPI_COMM_WORLD, 0, 1); }
   int health() { return nsx_.report_persistent_state(pcout); }
+  void paths() { nsx_.report_paths(std::cerr); }   // after the first solve_time_step, on every rank (MPI run with the internal layout: setup_mpi_with_layout)
   void solve_head() { nsx_.write_solution(solution_owned); }
   void assemble() {
     nsx_.assemble(NSX_TEMAM);

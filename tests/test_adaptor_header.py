@@ -49,7 +49,7 @@ def test_adaptor_calls_match_the_c_abi():
         assert name in decl, "%s is not declared in include/nsx.h" % name
         assert decl[name] == n, "%s called with %d arguments, declared with %d" % (name, n, decl[name])
     needed = {"nsx_create", "nsx_destroy", "nsx_set_tables", "nsx_set_mesh", "nsx_set_mesh_distributed", "nsx_comm_init_callbacks",
-              "nsx_set_internal_layout", "nsx_persistent_state", "nsx_assemble", "nsx_assemble_time_step", "nsx_apply_boundary_values", "nsx_solve_time_step",
+              "nsx_set_internal_layout", "nsx_persistent_state", "nsx_path_info", "nsx_assemble", "nsx_assemble_time_step", "nsx_apply_boundary_values", "nsx_solve_time_step",
               "nsx_prec_initialize", "nsx_prec_vmult", "nsx_export_block", "nsx_set_solution", "nsx_get_solution"}
     assert needed <= {n for n, _ in used}, needed - {n for n, _ in used}
 

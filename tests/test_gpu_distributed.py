@@ -28,6 +28,12 @@ def test_distributed_solve_equals_single_process(tmp_path, dim, level, world, n_
     d = np.load(out)
     if prec == 0:  # Yosida: the Schur CG of a distributed run is the two-launch one (nsx_cg.hip), not the launch-per-operation solver
         assert "cgd_A" in d["scopes"] and "cgd_B" in d["scopes"] and "spmv_S" not in d["scopes"], list(d["scopes"])
+    # every F->vmult of a distributed handle goes through the LDS-staged SpMV: the chunks without a ghost column while the exchange is in
+    # flight ("spmv_F"), the others behind it ("spmv_F_if"), the wait for the ghosts a scope of its own
+    info = dict(zip(d["path_keys"], d["path_info"]))
+    assert info["spmv_lds_staged"] == 1 and 0 < info["spmv_chunks_behind_halo"] <= info["spmv_chunks"], info
+    assert "spmv_F" in d["scopes"] and "spmv_F_if" in d["scopes"] and "halo_u_wait" in d["scopes"], list(d["scopes"])
+    assert info["neighbours"] >= 1 and info["ghost_nodes"] > 0
     # single-process reference with the same world * n_sub virtual ranks
     from navierstokes_project_nm4pde_amd import nsx
     from navierstokes_project_nm4pde_amd.frontend import DoFs, Mesh, Tables
@@ -252,3 +258,111 @@ def test_masked_streams_keep_the_collective_inside_the_larger_grids():
     assert np.abs(x0 - x1).max() < 1e-9 * np.abs(x0).max()
     assert p1["fallbacks"] == 0 and p1["sweep_persistent"] and p1["dirty_mailbox_words"] == 0
     assert t1.get("mgs_sweep", {}).get("launches", 0) > 0 and t1.get("mgs_dots", {}).get("launches", 0) == 0
+
+
+@pytest.mark.parametrize("cap,entries", [(23, 10), (19, 12)])
+def test_masks_switch_on_by_themselves_for_the_larger_distributed_grids(cap, entries):
+    """k_mgs_one<10,8,true> / <12,6,true>: what the 10.6 M-DoF mesh on 8 GPUs runs (11.1 entries per thread).  NSX_MGS_MAXWG caps the
+    grids so that the 54 043-DoF mesh needs 9-10 / 11-12 entries per thread: the 8-entry grid does not hold the vectors, so with the
+    DEFAULT NSX_COMM_CU_RESERVE the ranks agree to mask their streams (compute: all CUs but one per XCD; communication: those eight)
+    and the larger instantiation keeps the collective inside, with a real RCCL kernel (self-addressed send / receive) in front of it.
+    Persistent, no fall-back, the two-pass sweep's history and solution."""
+    from navierstokes_project_nm4pde_amd import nsx
+    from navierstokes_project_nm4pde_amd.frontend import DoFs, Mesh, Tables
+    from navierstokes_project_nm4pde_amd.problem import InletVelocity, cylinder_boundary_values
+    mesh = Mesh.cylinder(3, 2).partition(1, 8)
+    dofs, tables = DoFs(mesh, "colour"), Tables(3)
+    out = []
+    for env in ({"NSX_MGS_DIST": "0"}, {"NSX_MGS_MAXWG": str(cap), "NSX_EXT_SELF_P2P": "1"}):
+        os.environ.update(env)
+        try:
+            dev = nsx.Nsx(dofs, tables, 1e-3, 2e-4)
+            dev.comm_init_single()
+            dev.set_solution(np.zeros(dofs.n_dofs))
+            dev.assemble(nsx.TEMAM)
+            dev.apply_boundary_values(*cylinder_boundary_values(dofs, InletVelocity(3), 2e-4))
+            dev.profile(True)
+            st = dev.solve_time_step(nsx.ASIMPLE, tol_abs=1e-10, inner_rtol=1e-8)
+            out.append((st, dev.solution_owned.copy(), dev.profile_table(), dev.persistent_state(), dev.path_info()))
+            if "NSX_MGS_MAXWG" in env:
+                # a second communicator on the same handle: the masked stream belonged to the first one (the handle is back on all CUs),
+                # the new one asks for it again and the sweep stays persistent
+                dev.comm_init_single()
+                assert dev.path_info()["cus_reserved"] == 0
+                dev.set_solution(np.zeros(dofs.n_dofs))
+                st2 = dev.solve_time_step(nsx.ASIMPLE, tol_abs=1e-10, inner_rtol=1e-8)
+                i2, p2 = dev.path_info(), dev.persistent_state()
+                assert st2["status"] == 0 and abs(st2["outer_iterations"] - st["outer_iterations"]) <= 1
+                assert i2["cus_reserved"] == 8 and i2["sweep_collective_inside"] == 1 and p2["fallbacks"] == 0 and p2["sweep_persistent"]
+            dev.close()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    (s0, x0, t0, p0, i0), (s1, x1, t1, p1, i1) = out
+    assert i1["cus_reserved"] == 8 and i1["sweep_entries_per_thread_max"] == entries and i1["sweep_collective_inside"] == 1, i1
+    assert s0["status"] == 0 and s1["status"] == 0
+    for key in ("outer_iterations", "inner_F_iterations", "inner_S_iterations"):
+        assert abs(s0[key] - s1[key]) <= max(1, 0.02 * s0[key]), key
+    assert np.abs(x0 - x1).max() < 1e-9 * np.abs(x0).max()
+    assert p1["fallbacks"] == 0 and p1["sweep_persistent"] and p1["dirty_mailbox_words"] == 0
+    assert t1.get("mgs_sweep", {}).get("launches", 0) > 0 and t1.get("mgs_dots", {}).get("launches", 0) == 0
+
+
+def test_a_collective_that_comes_too_late_for_one_ranks_grid_keeps_the_ranks_in_step():
+    """NSX_EXT_LATE_RELEASE=k: the k-th collective inside a sweep never tells its grid that it is complete -- to ONE rank that is a
+    collective arriving after the bounded wait (8 s), while its peers' grids may have gone on.  The rank must not change its collective
+    sequence on its own: it finishes that sweep from the sums the late collective delivered (no further collective), asks all ranks
+    through the next sweep's collective to leave the persistent path, and everybody continues on the two-pass sweep.  Two events are
+    counted, the history and the solution are the two-pass sweep's, and a second communicator on the same handle starts afresh."""
+    from navierstokes_project_nm4pde_amd import nsx
+    from navierstokes_project_nm4pde_amd.frontend import DoFs, Mesh, Tables
+    from navierstokes_project_nm4pde_amd.problem import InletVelocity, cylinder_boundary_values
+    mesh = Mesh.cylinder(3, 1).partition(1, 4)
+    dofs, tables = DoFs(mesh, "colour"), Tables(3)
+    out = []
+    for env in ({"NSX_MGS_DIST": "0"}, {"NSX_EXT_LATE_RELEASE": "7"}):
+        os.environ.update(env)
+        try:
+            dev = nsx.Nsx(dofs, tables, 1e-3, 2e-4)
+            dev.comm_init_single()
+            dev.set_solution(np.zeros(dofs.n_dofs))
+            dev.assemble(nsx.TEMAM)
+            dev.apply_boundary_values(*cylinder_boundary_values(dofs, InletVelocity(3), 2e-4))
+            dev.profile(True)
+            st = dev.solve_time_step(nsx.ASIMPLE, tol_abs=1e-10, inner_rtol=1e-8)
+            rec = [st, dev.solution_owned.copy(), dev.profile_table(), dev.persistent_state(), dev.comm_counters()]
+            if "NSX_EXT_LATE_RELEASE" in env:   # a new communicator on the same handle: the sweep's path is chosen again
+                dev.comm_init_single()
+                st2 = dev.solve_time_step(nsx.ASIMPLE, tol_abs=1e-10, inner_rtol=1e-8)
+                rec.append(st2)
+            out.append(rec)
+            dev.close()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    (s0, x0, t0, p0, c0), (s1, x1, t1, p1, c1, s2) = out
+    assert s0["status"] == 0 and s1["status"] == 0 and s2["status"] == 0
+    for key in ("outer_iterations", "inner_F_iterations", "inner_S_iterations"):
+        assert abs(s0[key] - s1[key]) <= max(1, 0.02 * s0[key]), key
+    assert np.abs(x0 - x1).max() < 1e-9 * np.abs(x0).max()
+    assert p1["fallbacks"] == 2 and not p1["sweep_persistent"]       # the late collective, then the agreed exit
+    assert t1.get("mgs_sweep", {}).get("launches", 0) == 8 and t1.get("mgs_dots", {}).get("launches", 0) > 0
+    # no collective was added or lost on the way: 7 sweeps with one collective each, the leave sweep (one inside + its two-pass redo), two passes after
+    assert abs(c1[0] - c0[0]) <= 12, (c0, c1)   # (+ the ranks' agreements on the path: once per handle and per role of a vector)
+
+
+def test_rccl_ghost_exchange_branch_runs_with_the_rank_as_its_own_neighbour():
+    """comm_halo_begin / comm_halo_finish over RCCL: pack kernel on the communication stream, grouped ncclSend / ncclRecv straight into
+    the ghost region, event, wait of the compute stream.  RCCL refuses two ranks on one device, so the multi-process tests of this
+    file exchange through host callbacks; here the RCCL branch itself runs, on a 1-rank communicator whose only neighbour is the
+    rank itself (a real launch of RCCL's point-to-point kernel), for 1, 2 and 3 values per node and three exchanges in a row."""
+    from navierstokes_project_nm4pde_amd import nsx
+    from navierstokes_project_nm4pde_amd.frontend import DoFs, Mesh, Tables
+    mesh = Mesh.cylinder(3, 1).partition(1, 4)
+    dev = nsx.Nsx(DoFs(mesh), Tables(3), 1e-3, 2e-4)
+    dev.comm_init_single()
+    h0 = dev.comm_counters()[1]
+    for n_own, n_ghost, ncomp in ((1000, 37, 1), (5000, 4999, 3), (120000, 30000, 3), (777, 2000, 2)):
+        assert dev.comm_self_halo_test(n_own, n_ghost, ncomp) == 0.0, (n_own, n_ghost, ncomp)
+    assert dev.comm_counters()[1] - h0 == 12
+    dev.close()

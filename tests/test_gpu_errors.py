@@ -435,3 +435,69 @@ def test_norm_after_the_sweep_from_the_gram_matrix(prob):
     assert abs(nf[k] - true_n2[k]) > 1e-6 * true_n2[k]                     # the formula alone: a difference of numbers 1e14 times larger
     assert np.abs(Hd - Hx).max() <= 1e-12 * np.abs(Hx).max()
     dev.close()
+
+
+@pytest.mark.parametrize("cap,entries", [(23, 10), (19, 12)])
+def test_larger_sweep_instantiations_equal_the_launch_per_link_chain(cap, entries):
+    """k_mgs_one<10,8> and <12,6> (10 / 12 entries per thread, 8 / 6 basis vectors in registers) are what one GPU runs between 1.05 M
+    and 1.57 M velocity entries; NSX_MGS_MAXWG caps the resident grid so that the 54 043-DoF mesh needs them (51 558 entries over
+    23 x 256 threads: 9; over 19 x 256: 11).  Same history and solution as the chain of separate launches (NSX_MGS=0), and the
+    handle says which instantiation ran."""
+    p = Problem("cylinder", 3, 2, n_sub=8, ordering="colour")
+    res = []
+    for env in ({"NSX_MGS": "0"}, {"NSX_MGS_MAXWG": str(cap)}):
+        os.environ.update(env)
+        try:
+            dev, _ = _assembled(p)
+            st = dev.solve_time_step(3, tol_abs=1e-10, inner_rtol=1e-8)
+            res.append((st, dev.solution_owned.copy(), dev.path_info(), dev.persistent_state()))
+            dev.close()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    (s0, x0, i0, _), (s1, x1, i1, p1) = res
+    assert i0["sweep_entries_per_thread_max"] == 0 and i1["sweep_entries_per_thread_max"] == entries, (i0, i1)
+    assert i1["sweep_grid"] <= cap and p1["fallbacks"] == 0 and p1["sweep_persistent"]
+    assert s0["status"] == 0 and s0["outer_iterations"] > 5
+    for key in ("outer_iterations", "inner_F_iterations", "inner_S_iterations"):
+        assert abs(s0[key] - s1[key]) <= max(1, 0.02 * s0[key]), key
+    assert np.abs(x0 - x1).max() < 1e-9 * np.abs(x0).max()
+
+
+@pytest.mark.parametrize("ranks", [600, 1100])
+def test_schur_cg_in_two_launches_on_one_gpu_with_more_blocks_than_resident_workgroups(ranks):
+    """More Schur ILU blocks than the persistent CG's resident grid holds (512): one GPU then runs the two launches per iteration of
+    the distributed path (k_cgd_A / k_cgd_B); above 1024 blocks their per-block partial sums go through k_cgd_fold (the 10.6 M-DoF
+    mesh on one GPU has 4 833 blocks).  Same CG iteration counts and solution as the launch-per-operation solver (NSX_CG_FUSED=0)."""
+    import navierstokes_project_nm4pde_amd.nsx as nsx
+    p = Problem("cylinder", 3, 3, ordering="first_touch")
+    res = []
+    for env in ({"NSX_CG_FUSED": "0"}, {}):
+        os.environ.update(env)
+        try:
+            dev = p.device()
+            dev.set_internal_layout(ranks, nsx.COLOUR, 0)
+            dev.set_solution(p.smooth_velocity())
+            dev.assemble(nsx.TEMAM)
+            dev.apply_boundary_values(*_bc(p, p.deltat))
+            dev.profile(True)
+            dev.prec_initialize(0)
+            src = np.random.default_rng(3).standard_normal(p.dofs.n_dofs)
+            y, st = dev.prec_vmult(0, src, inner_rtol=1e-10)
+            t = dev.solve_time_step(0)
+            res.append((st, y, t, dev.solution_owned.copy(), dev.profile_table(), dev.path_info()))
+            dev.close()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    (s0, y0, t0, x0, tab0, i0), (s1, y1, t1, x1, tab1, i1) = res
+    assert i1["schur_blocks"] > 512 and (ranks < 1024 or i1["schur_blocks"] > 1024), i1
+    assert i0["schur_cg_path"] == 1 and i1["schur_cg_path"] == 3, (i0, i1)
+    assert tab1.get("cgd_A", {}).get("launches", 0) > 0 and tab1.get("cgd_B", {}).get("launches", 0) > 0
+    assert tab1.get("spmv_S", {}).get("launches", 0) == 0 and tab0.get("spmv_S", {}).get("launches", 0) > 0
+    assert s0["status"] == 0 and s1["status"] == 0
+    assert s0["inner_S_iterations"] > 10 and abs(s0["inner_S_iterations"] - s1["inner_S_iterations"]) <= max(1, 0.02 * s0["inner_S_iterations"])
+    assert np.abs(y0 - y1).max() < 1e-8 * np.abs(y0).max()
+    for key in ("outer_iterations", "inner_S_iterations"):
+        assert abs(t0[key] - t1[key]) <= max(1, 0.05 * t0[key]), key
+    assert np.abs(x0 - x1).max() < 1e-3 * np.abs(x0).max()

@@ -109,6 +109,9 @@ def test_preconditioner_initialize_matches_oracle(pair, prec):
     assert rel_err(dev.ilu(1)[2], ora.ilu_S(S_o.nnz)) < 1e-10
 
 
+VMULT_TIGHT_MAX = 8e-14   # measured maximum (round 5, MI355X, 9 cases x 4 preconditioners: 7.7e-14; gpurun_out/parity_maxima.jsonl, "prec_vmult_tight")
+
+
 @pytest.mark.parametrize("prec", [0, 1, 2, 3])
 def test_preconditioner_vmult_tight_matches_oracle(pair, prec):
     p, dev, ora = pair
@@ -118,7 +121,11 @@ def test_preconditioner_vmult_tight_matches_oracle(pair, prec):
     yd, sd = dev.prec_vmult(prec, src, inner_rtol=1e-11)
     yo, so = ora.prec_vmult(prec, src, inner_rtol=1e-11)
     assert sd["status"] == 0 and so["status"] == 0
-    assert rel_err(yd, yo) < 1e-8
+    err = rel_err(yd, yo)
+    record("prec_vmult_tight", case=p.case_id, prec=prec, err=err)
+    # measured maximum over the 9 cases x 4 preconditioners: see VMULT_TIGHT_MAX below (two inner Krylov solves to 1e-11 in a row, each
+    # stopping one iteration earlier or later by rounding); asserted at 100 x that
+    assert err < 100 * VMULT_TIGHT_MAX, err
 
 
 @pytest.mark.parametrize("prec", [0, 3])
