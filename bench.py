@@ -55,7 +55,7 @@ BIG_STEPS, BIG_WARMUP, BIG_SPINUP = _BIG_SCHEDULE or (6, 1, 3)  # schedule of th
                                              # this mesh still takes seconds, and the whole invocation has to stay within minutes)
 PMC_PROFILE = "profiles/r04_pmc_fetch_write_per_kernel.json"
 LAYOUT_PROFILE = "profiles/r04_layout_iterations.json"
-BIG_BASE_PROFILE = "profiles/r04_strong_10M_one_gpu.json"
+BIG_BASE_PROFILE = "profiles/r05_strong_10M_one_gpu.json"
 STEP_HISTORY = "profiles/r04_step_history.txt"
 NU, DT = 1e-3, 2e-4
 
@@ -708,7 +708,7 @@ def main():
                "persistent_fallbacks": max(s.get("persistent_fallbacks", 0) for s in stats_b),
                "dof_steps_per_s_in_units_of_the_1M_mesh": BIG_STEPS / el_b * dofs_b.n_dofs / BASE_DOFS}
         base = committed_big_base()
-        if base and base.get("n_dofs") == dofs_b.n_dofs:  # (not in a rehearsal of this leg on another mesh)
+        if base and base.get("n_dofs") == dofs_b.n_dofs and (base.get("steps"), base.get("warmup"), base.get("spinup_steps")) == (BIG_STEPS, BIG_WARMUP, BIG_SPINUP):  # (not in a rehearsal of this leg on another mesh / schedule)
             big["one_gpu_base"] = base
             big["speedup_over_one_gpu"] = big["time_steps_per_s"] / base["value"] if base.get("value") else None
             big["speedup_per_outer_iteration"] = base["ms_per_outer_iteration"] / big["ms_per_outer_iteration"] if base.get("ms_per_outer_iteration") else None

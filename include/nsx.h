@@ -220,8 +220,10 @@ int nsx_persistent_state(nsx_handle *h, int state[4]);
  * [16] / [17] entries per thread of the sweep instantiation an RCCL run WOULD use for the velocity vector on plain / on CU-masked
  * streams (0: the resident grid does not hold it: two passes), [18] / [19] the same for the block vector, [20] Schur blocks per
  * entry of a partial-sum array of the two-launch CG (1: no fold launch), [21] the velocity sweep's instantiation on one GPU without a
- * communicator, [22] / [23] P2 / P1 nodes this handle owns. */
-int nsx_path_info(nsx_handle *h, int info[24]);
+ * communicator, [22] / [23] P2 / P1 nodes this handle owns, [24] 1 = the last persistent sweep had the triangular solves of the velocity
+ * ILU(0) inside its launch (k_ilu_mgs: PreconditionILU::vmult + the orthogonalisation of one inner GMRES iteration, reference
+ * Preconditioners.hpp:382,405, as ONE kernel), [25] such launches so far; [26..31] reserved (0). */
+int nsx_path_info(nsx_handle *h, int info[32]);
 
 /* SolverGMRES' orthogonalisation (deal.II's modified Gram-Schmidt add_and_dot chain inside every solver.solve of the path: reference
  * NavierStokes3D.cpp:574, Preconditioners.hpp:173,273,288,382,405) on the caller's vectors, through the very sweep kernel the solvers

@@ -161,7 +161,7 @@ public:
   // ghost column while the Epetra_Import-equivalent exchange is in flight, the others behind it), the Schur CG's variant (1 one launch
   // per operation, 2 one persistent launch, 3 two launches per iteration), neighbours and ghost nodes.  One line per rank.
   void report_paths(std::ostream &out) const {
-    int p[24];
+    int p[32];
     ck(h, nsx_path_info(h, p));
     out << "nsx rank " << rank << ": LDS-staged SpMV " << p[0] << " (" << p[1] << " chunks, " << p[2] << " behind the ghost exchange), sweep " << p[3]
         << " entries per thread on " << p[4] << " workgroups, Schur CG path " << p[8] << " on " << p[9] << " blocks, " << p[10] << " neighbours, " << p[12]

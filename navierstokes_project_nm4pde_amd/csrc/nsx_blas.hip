@@ -9,6 +9,7 @@
 // Multi-GPU: every rank leaves the same number of partial sums, they are all-reduced element-wise over RCCL
 // (comm_allreduce_partials) and consumed exactly as on one GPU.
 #include "nsx_grid.hpp"
+#include "nsx_ilu_lanes.hpp"
 
 namespace nsx {
 
@@ -1019,6 +1020,373 @@ __global__ __launch_bounds__(256) void k_mgs_one(int n, int split, int gap, doub
   MGS_STAMP();  // stores issued
 }
 
+// ---- the triangular solves of the preconditioner AND the sweep in ONE launch (round 5) ------------------------------------------
+// An inner GMRES iteration on F is  p = F v_k (SpMV)  ->  z = (LU)^-1 p (k_ilu_solve_lanes: one wave per ~8 rank blocks, their rows
+// in LDS)  ->  sweep of z against the basis (k_mgs_one).  The last two hand z to each other through HBM, and while the sweeping wave
+// of the solve works through its ~120 ticks the device moves nothing, while the sweep then spends its first 11-17 us loading basis
+// vectors with every wave stalled.  Here workgroup b of the persistent grid IS wave b of the solve's schedule (same stream, same ticks,
+// same arithmetic: z is bit for bit the separate kernel's): its four waves load the right-hand side rows into LDS, wave 0 runs the two
+// sweeps while waves 1-3 request their entries of the basis vectors, and after a barrier every thread takes its entries of z from
+// LDS -- z never travels through memory -- and the kernel goes on as k_mgs_one: one grid exchange, the coefficients from the Gram
+// matrix, update, norm, normalisation.  Entry -> thread: entry e of the workgroup's rows (LDS order) belongs to thread e % 256, so a
+// workgroup needs at most 256 * E / NCOMP rows (853 with E = 10; the bench layout's largest wave has 747).  Sums are fixed-order but
+// taken in another grouping than k_mgs_one's (entries are dealt by rank block, not striped over the vector): same history class, other
+// last bits.  No static __shared__ object: the solve's stream holds absolute LDS addresses (nsx_ilu_lanes.hpp), its rows sit at address 0.
+struct IluMgsArgs {
+  const int32_t *row_ptr, *rows, *slab_ptr;
+  const uint32_t *meta;
+  const double *val, *dinv, *rhs;
+  int ilu_doubles;  // LDS doubles reserved for the solve's rows (+ 64 scratch rows), the sweep's arrays follow
+  int split_simd;   // 1: the sweeping wave of the second half of the grid is wave 2 (see the kernel)
+  unsigned long long *trace;  // development (NSX_ILU_MGS_TRACE): 16 wall-clock stamps per wave, or null
+  int pre_sleep, stage_sleep;  // units of ~0.5 us the non-sweeping waves wait before their first request / between two basis vectors (NSX_ILU_MGS_PRE, _STAGE)
+};
+__device__ __forceinline__ void im_sleep(int units) {
+  for (int q = 0; q < units; ++q) __builtin_amdgcn_s_sleep(16);  // 16 x 64 cycles ~ 0.5 us at 2.1 GHz
+}
+#define IM_STAMP(k)                                                                                                   \
+  do {                                                                                                                \
+    if (I.trace && lane == 0) I.trace[((size_t)wg * 4 + wave) * 16 + (k)] = wall_clock64();                             \
+  } while (0)
+template <int NCOMP, int EI, int PF, int E, int DMAX>
+__global__ __launch_bounds__(256) void k_ilu_mgs(int n, double *__restrict__ w, MgsArgs V, int dim, double *__restrict__ gram, unsigned long long *box,
+                                                 unsigned long long *box_next, int reset_words, double *__restrict__ scal_out, int *err_host, unsigned long long *tail,
+                                                 int normalize, int consider, double *pub_vals, unsigned long long *pub_flag, unsigned long long seq, int drop_wg,
+                                                 double norm_guard, IluMgsArgs I) {
+  extern __shared__ double xs[];
+  double *sh = xs + I.ilu_doubles;                 // [4][MGS_ONE_VALS]
+  double *tot = sh + 4 * MGS_ONE_VALS;             // [MGS_ONE_VALS]
+  double *G = tot + MGS_ONE_VALS;                  // [MGS_STEPS][MGS_STEPS + 1]
+  double *hc = G + MGS_STEPS * (MGS_STEPS + 1);    // [MGS_STEPS]
+  double *s_norm2 = hc + MGS_STEPS;
+  int *s_err = (int *)(s_norm2 + 1);
+  double *stage = s_norm2 + 2;                     // [DMAX][E][64]: the sweeping wave's entries of the basis
+  const int nwg = gridDim.x, wg = blockIdx.x, T = nwg * 256, t = wg * 256 + threadIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool lds_ok = (uint32_t)(uintptr_t)(lds_f64 *)xs == 0u;  // uniform over the grid: everybody leaves, nobody waits
+  if (!lds_ok) {
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(err_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (wg == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(pub_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    return;
+  }
+  if (threadIdx.x == 0) *s_err = 0;
+  IM_STAMP(0);  // start
+  unsigned long long *total = box + (size_t)MGS_ONE_VALS * MGS_MAX_WG, *total_next = box_next + (size_t)MGS_ONE_VALS * MGS_MAX_WG;
+  for (int q = t; q < reset_words; q += T) box_next[q] = GX_EMPTY;
+  if (wg == 0 && threadIdx.x < MGS_ONE_VALS) total_next[threadIdx.x] = GX_EMPTY;
+  const int nvals = 2 * dim + 1;
+  // ---- the workgroup's rows: wave `wg` of the solve's schedule
+  const int rb = I.row_ptr[wg], nr = I.row_ptr[wg + 1] - rb, ne = nr * NCOMP;
+  const int s0 = I.slab_ptr[2 * wg], s1 = I.slab_ptr[2 * wg + 1], s2 = I.slab_ptr[2 * wg + 2];
+  int idx[E];
+#pragma unroll
+  for (int k = 0; k < E; ++k) {
+    const int e = (int)threadIdx.x + 256 * k;
+    const int r_ = e < ne ? I.rows[rb + e / NCOMP] : -1;
+    idx[k] = r_ >= 0 ? r_ * NCOMP + e % NCOMP : -1;
+  }
+  {
+    double y[E];
+#pragma unroll
+    for (int k = 0; k < E; ++k) y[k] = idx[k] >= 0 ? I.rhs[idx[k]] : 0.0;
+#pragma unroll
+    for (int k = 0; k < E; ++k)
+      if (idx[k] >= 0) xs[(int)threadIdx.x + 256 * k] = y[k];
+  }
+  if (wave == 0) {
+#pragma unroll
+    for (int c = 0; c < NCOMP; ++c) xs[(nr + lane) * NCOMP + c] = 0.0;  // the scratch rows of the idle slots
+  }
+  __syncthreads();
+  IM_STAMP(1);  // right-hand side rows in LDS
+  // which wave sweeps: the two workgroups a CU holds (b and b + nwg / 2 under the dispatcher's round-robin) put their sweeping waves on
+  // different SIMDs (a wave's SIMD is its number in the workgroup): a tick is a chain of dependent LDS trips, two of them on one SIMD
+  // take turns at its issue port
+  const int iw = (I.split_simd && 2 * wg >= nwg) ? 2 : 0;
+  if (wave == iw) {  // the two sweeps of the triangular solve, exactly k_ilu_solve_lanes'
+    const uint32_t scratch = (uint32_t)(nr + lane) * (8u * NCOMP);
+    LaneSlot<EI> A[PF];
+    lane_load<EI, PF>(A, s0, I.meta, I.val, (unsigned)lane);
+    lane_sweep<NCOMP, EI, PF>(A, s0, s1, I.meta, I.val, (unsigned)lane, scratch);  // y = L^{-1} b
+    IM_STAMP(2);  // forward sweep done
+    lane_load<EI, PF>(A, s1, I.meta, I.val, (unsigned)lane);
+    for (int base = 0; base < nr; base += 64 * 4) {  // y *= D^{-1}
+      double d[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int q = base + 64 * k + lane;
+        d[k] = q < nr ? I.dinv[rb + q] : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int q = base + 64 * k + lane;
+        if (q < nr) {
+#pragma unroll
+          for (int c = 0; c < NCOMP; ++c) xs[q * NCOMP + c] *= d[k];
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    lane_sweep<NCOMP, EI, PF>(A, s1, s2, I.meta, I.val, (unsigned)lane, scratch);  // x = U^{-1} y
+    IM_STAMP(3);  // backward sweep done
+  }
+  // ---- the basis.  The three waves that do not sweep get here at once: their requests fly while the fourth sweeps.  The sweeping
+  // wave's OWN entries of the basis would be requested behind its sweeps and arrive 6 - 7 us later with the whole workgroup waiting at
+  // the barrier (profiles/r05_ilu_mgs_timeline.txt): the other three fetch them as well, into LDS (`stage`, [vector][k][lane]).
+  double wv[E], vb[DMAX][E];
+  const int j_keep = dim > DMAX ? dim - DMAX : 0;
+  if (wave != iw) {
+    im_sleep(I.pre_sleep);
+#pragma unroll
+    for (int i = 0; i < DMAX; ++i) {
+      const double *__restrict__ vp = j_keep + i < dim ? V.v[j_keep + i] : nullptr;
+#pragma unroll
+      for (int k = 0; k < E; ++k) vb[i][k] = (vp && idx[k] >= 0) ? ld_stream<1>(vp + idx[k]) : 0.0;
+      if (I.stage_sleep) {
+        asm volatile("" ::: "memory");
+        im_sleep(I.stage_sleep);
+      }
+    }
+    constexpr int HB = (64 * E + 191) / 192;
+    const int hid = (wave < iw ? wave : wave - 1) * 64 + lane;  // 0 .. 191
+    int gi[HB];
+#pragma unroll
+    for (int m = 0; m < HB; ++m) {
+      const int q = hid + 192 * m, e = 64 * iw + (q & 63) + 256 * (q >> 6);
+      const int r_ = (q < 64 * E && e < ne) ? I.rows[rb + e / NCOMP] : -1;
+      gi[m] = r_ >= 0 ? r_ * NCOMP + e % NCOMP : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < DMAX; ++i) {
+      const double *__restrict__ vp = j_keep + i < dim ? V.v[j_keep + i] : nullptr;
+      double tmp[HB];
+#pragma unroll
+      for (int m = 0; m < HB; ++m) tmp[m] = (vp && gi[m] >= 0) ? ld_stream<1>(vp + gi[m]) : 0.0;
+#pragma unroll
+      for (int m = 0; m < HB; ++m)
+        if (hid + 192 * m < 64 * E) stage[i * (64 * E) + hid + 192 * m] = tmp[m];
+    }
+  }
+  if (I.trace) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    IM_STAMP(4);  // this wave's requests have arrived
+  }
+  __syncthreads();  // z is complete in LDS, and so is the sweeping wave's part of the basis
+  IM_STAMP(5);
+  if (wave == iw) {
+#pragma unroll
+    for (int i = 0; i < DMAX; ++i)
+#pragma unroll
+      for (int k = 0; k < E; ++k) vb[i][k] = stage[(i * E + k) * 64 + lane];
+  }
+#pragma unroll
+  for (int k = 0; k < E; ++k) wv[k] = idx[k] >= 0 ? xs[(int)threadIdx.x + 256 * k] : 0.0;
+  double vl[E];
+#pragma unroll
+  for (int k = 0; k < E; ++k) vl[k] = 0.0;
+#pragma unroll
+  for (int i = 0; i < DMAX; ++i)
+    if (j_keep + i == dim - 1) {
+#pragma unroll
+      for (int k = 0; k < E; ++k) vl[k] = vb[i][k];
+    }
+  auto wave_post = [&](int v, double a) {
+    const double s_ = gx_wave_sum(a);
+    if (lane == 0) sh[wave * MGS_ONE_VALS + v] = s_;
+  };
+  {
+    double a = 0.0;
+#pragma unroll
+    for (int k = 0; k < E; ++k) a += wv[k] * wv[k];
+    wave_post(2 * dim, a);
+  }
+  for (int j = 0; j < j_keep; ++j) {  // older vectors: streamed, not kept (dim > DMAX only)
+    const double *__restrict__ vp = V.v[j];
+    double ar = 0.0, ag = 0.0;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+      const double x_ = idx[k] >= 0 ? ld_twice(vp + idx[k]) : 0.0;
+      ar += wv[k] * x_;
+      ag += vl[k] * x_;
+    }
+    wave_post(j, ar);
+    wave_post(dim + j, ag);
+  }
+#pragma unroll
+  for (int i = 0; i < DMAX; ++i)
+    if (j_keep + i < dim) {
+      double ar = 0.0, ag = 0.0;
+#pragma unroll
+      for (int k = 0; k < E; ++k) {
+        ar += wv[k] * vb[i][k];
+        ag += vl[k] * vb[i][k];
+      }
+      wave_post(j_keep + i, ar);
+      wave_post(dim + j_keep + i, ag);
+    }
+  __syncthreads();
+  IM_STAMP(6);  // local sums done
+  // ---- hop 1: mailboxes; value v is summed by workgroup v % nwg
+  int lerr = 0;
+  for (int v = threadIdx.x; v < nvals; v += 256)
+    if (wg != drop_wg) gx_post(box + (size_t)v * nwg + wg, (sh[v] + sh[MGS_ONE_VALS + v]) + (sh[2 * MGS_ONE_VALS + v] + sh[3 * MGS_ONE_VALS + v]));
+  for (int v = wg; v < nvals; v += nwg) {
+    double a = 0.0;
+    for (int q = threadIdx.x; q < nwg; q += 256) a += gx_wait_value(box + (size_t)v * nwg + q, &lerr);
+    if (lerr) *s_err = 1;
+    __syncthreads();
+    const double s_ = gx_wave_sum(a);
+    if (lane == 0) sh[wave * MGS_ONE_VALS] = s_;
+    __syncthreads();
+    if (threadIdx.x == 0 && !*s_err) gx_post(total + v, (sh[0] + sh[MGS_ONE_VALS]) + (sh[2 * MGS_ONE_VALS] + sh[3 * MGS_ONE_VALS]));
+    __syncthreads();
+  }
+  // ---- hop 2: everybody picks up the totals
+  for (int v = threadIdx.x; v < nvals; v += 256) {
+    tot[v] = gx_wait_value(total + v, &lerr);
+    if (lerr) *s_err = 1;
+  }
+  __syncthreads();
+  IM_STAMP(7);  // totals picked up
+  bool dead = *s_err != 0;
+  double xo[E];
+#pragma unroll
+  for (int k = 0; k < E; ++k) xo[k] = (!dead && j_keep > 0 && idx[k] >= 0) ? ld_twice(V.v[0] + idx[k]) : 0.0;
+  if (!dead) {
+    for (int q = threadIdx.x; q < (dim - 1) * MGS_STEPS; q += 256) {
+      const int r_ = q / MGS_STEPS, c_ = q % MGS_STEPS;
+      if (c_ <= r_) G[r_ * (MGS_STEPS + 1) + c_] = gram[r_ * 32 + c_];
+    }
+    if ((int)threadIdx.x < dim) G[(dim - 1) * (MGS_STEPS + 1) + threadIdx.x] = tot[dim + threadIdx.x];
+    __syncthreads();
+    if (wave == 0) {
+      double hj = 0.0;
+      const int col = lane < dim ? lane : 0;
+      double g_cur = G[col], t_cur = tot[0];
+      for (int j = 0; j < dim; ++j) {
+        const int jn = j + 1 < dim ? j + 1 : j;
+        const double g_next = G[jn * (MGS_STEPS + 1) + col], t_next = tot[jn];
+        double part = (lane < j) ? g_cur * hj : 0.0;
+        part = gx_wave_sum(part);
+        if (lane == j) hj = t_cur - part;
+        g_cur = g_next;
+        t_cur = t_next;
+      }
+      if (lane < dim) hc[lane] = hj;
+      double quad = 0.0;
+      if (lane < dim) {
+        double row = 0.0;
+        for (int i = 0; i < dim; ++i) row += (i <= lane ? G[lane * (MGS_STEPS + 1) + i] : G[i * (MGS_STEPS + 1) + lane]) * __shfl(hj, i, 64);
+        quad = hj * (row - 2.0 * tot[lane]);
+      } else {
+        for (int i = 0; i < dim; ++i) (void)__shfl(hj, i, 64);
+      }
+      quad = gx_wave_sum(quad);
+      if (lane == 0) *s_norm2 = tot[2 * dim] + quad;
+    }
+    __syncthreads();
+    for (int j = 0; j < j_keep; ++j) {
+      double xn[E];
+#pragma unroll
+      for (int k = 0; k < E; ++k) xn[k] = (j + 1 < j_keep && idx[k] >= 0) ? ld_twice(V.v[j + 1] + idx[k]) : 0.0;
+      const double alpha = -1.0 * hc[j];
+#pragma unroll
+      for (int k = 0; k < E; ++k)
+        if (idx[k] >= 0) wv[k] += alpha * xo[k];
+#pragma unroll
+      for (int k = 0; k < E; ++k) xo[k] = xn[k];
+    }
+#pragma unroll
+    for (int i = 0; i < DMAX; ++i)
+      if (j_keep + i < dim) {
+        const double alpha = -1.0 * hc[j_keep + i];
+#pragma unroll
+        for (int k = 0; k < E; ++k) wv[k] += alpha * vb[i][k];
+      }
+    double norm2 = *s_norm2;
+    const double w2 = tot[2 * dim];
+    if (!(norm2 > norm_guard * w2)) {  // uniform over the grid: a second exchange sums |w'|^2 itself
+      double a = 0.0;
+#pragma unroll
+      for (int k = 0; k < E; ++k) a += wv[k] * wv[k];
+      const double s_ = gx_wave_sum(a);
+      __syncthreads();
+      if (lane == 0) sh[wave * MGS_ONE_VALS] = s_;
+      __syncthreads();
+      const int v = 2 * dim + 1;
+      if (threadIdx.x == 0 && wg != drop_wg) gx_post(box + (size_t)v * nwg + wg, (sh[0] + sh[MGS_ONE_VALS]) + (sh[2 * MGS_ONE_VALS] + sh[3 * MGS_ONE_VALS]));
+      if (wg == v % nwg) {
+        double b = 0.0;
+        for (int q = threadIdx.x; q < nwg; q += 256) b += gx_wait_value(box + (size_t)v * nwg + q, &lerr);
+        if (lerr) *s_err = 1;
+        __syncthreads();
+        const double sb = gx_wave_sum(b);
+        if (lane == 0) sh[wave * MGS_ONE_VALS + 1] = sb;
+        __syncthreads();
+        if (threadIdx.x == 0 && !*s_err) gx_post(total + v, (sh[1] + sh[MGS_ONE_VALS + 1]) + (sh[2 * MGS_ONE_VALS + 1] + sh[3 * MGS_ONE_VALS + 1]));
+      }
+      if (threadIdx.x == 0) {
+        const double x_ = gx_wait_value(total + v, &lerr);
+        if (lerr) *s_err = 1;
+        *s_norm2 = x_;
+      }
+      __syncthreads();
+      dead = *s_err != 0;
+      norm2 = *s_norm2;
+    }
+    if (!dead && normalize) {
+      const double nrm = sqrt(norm2);
+      const bool second_sweep = consider && !(nrm > 10. * sqrt(w2) * 1.4901161193847656e-08);
+      if (nrm != 0.0 && !second_sweep) {
+        const double inv = 1. / nrm;
+#pragma unroll
+        for (int k = 0; k < E; ++k) wv[k] = inv * wv[k];
+      }
+    }
+  }
+  if (dead) {
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(err_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (wg == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(pub_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    return;
+  }
+  if (wg == 0) {
+    if ((int)threadIdx.x < dim) {
+      gram[(dim - 1) * 32 + threadIdx.x] = tot[dim + threadIdx.x];
+      scal_out[threadIdx.x] = hc[threadIdx.x];
+      __hip_atomic_store(pub_vals + threadIdx.x, hc[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (threadIdx.x == 0) {
+      scal_out[dim] = *s_norm2;
+      scal_out[dim + 1] = tot[2 * dim];
+      __hip_atomic_store(pub_vals + dim, *s_norm2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(pub_vals + dim + 1, tot[2 * dim], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(pub_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  IM_STAMP(8);  // coefficients, update, norm done
+  if (threadIdx.x == 0) tail[wg] = seq;
+#pragma unroll
+  for (int k = 0; k < E; ++k)
+    if (idx[k] >= 0) w[idx[k]] = wv[k];
+}
+// LDS of the fused kernel: the solve's rows + scratch rows, then sh, tot, G, hc, |w'|^2, the error word
+static size_t ilu_mgs_lds_doubles(int ilu_doubles, int e) {
+  const int dmax = e <= 8 ? 10 : e == 9 ? 9 : 8;
+  return (size_t)ilu_doubles + 4 * MGS_ONE_VALS + MGS_ONE_VALS + MGS_STEPS * (MGS_STEPS + 1) + MGS_STEPS + 2 + (size_t)dmax * e * 64;
+}
+
 // entries per thread x basis vectors kept in registers: 8 x 10, 10 x 8, 12 x 6 (round 4: 1.28 M velocity dofs per GPU -- the 10.6 M-DoF mesh
 // on 8 GPUs -- need 11.1 entries per thread of the 448-workgroup grid a distributed sweep may use; one GPU: vectors up to 1.57 M entries)
 static const void *mgs_one_fn(int e, bool dist = false) {
@@ -1160,6 +1528,7 @@ __global__ __launch_bounds__(256) void k_ls_dots(int n, int split, int gap, cons
     double ar[LS_C], ag[LS_C], aw = 0.0;
 #pragma unroll
     for (int k = 0; k < LS_C; ++k) ar[k] = ag[k] = 0.0;
+    // (two entries per thread and pass, 2 x (LS_C + 2) loads in flight, measured SLOWER at 10.2 M entries: 228 against 214 us)
     for (int i0 = blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += gridDim.x * 256) {
       const int i = i0 + (i0 >= split ? gap : 0);
       const double wi = w[i], li = vl[i];
@@ -1246,7 +1615,37 @@ __global__ __launch_bounds__(256) void k_ls_update(int n, int split, int gap, do
   if ((int)threadIdx.x < dim) hs[threadIdx.x] = -1.0 * coef[threadIdx.x];
   __syncthreads();
   double acc = 0.0;
-  for (int i0 = blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += gridDim.x * 256) {
+  // four entries per thread and pass: the grid is at most 512 workgroups (one partial sum each), so at 10 M entries a thread walks ~80
+  // of them, and taken one by one every basis vector was a dependent trip with a single load in flight (262 us per sweep at 10.2 M
+  // entries, 3.1 TB/s).  Same operations on every entry in the same order, same order of the squares in the thread's sum: bit-identical.
+  constexpr int U = 4;
+  const int stride = gridDim.x * 256;
+  int i0 = blockIdx.x * 256 + threadIdx.x;
+  for (; i0 + (U - 1) * stride < n; i0 += U * stride) {
+    int ii[U];
+    double wi[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int q = i0 + u * stride;
+      ii[u] = q + (q >= split ? gap : 0);
+      wi[u] = w[ii[u]];
+    }
+#pragma unroll 2
+    for (int j = 0; j < dim; ++j) {
+      const double *__restrict__ vj = V.v[j];
+      double x[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) x[u] = vj[ii[u]];
+#pragma unroll
+      for (int u = 0; u < U; ++u) wi[u] += hs[j] * x[u];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      w[ii[u]] = wi[u];
+      acc += wi[u] * wi[u];
+    }
+  }
+  for (; i0 < n; i0 += stride) {
     const int i = i0 + (i0 >= split ? gap : 0);
     double wi = w[i];
     for (int j = 0; j < dim; ++j) wi += hs[j] * V.v[j][i];
@@ -1315,9 +1714,61 @@ __global__ void k_ext_to_ls(int dim, const double *__restrict__ ext_vals, double
 static int mgs_role(const nsx_handle *h, Span sp) { return sp.split < sp.n ? 2 : sp.n == h->n_u ? 0 : sp.n == h->n_p ? 1 : 3; }
 
 // out[0..dim) = h(i), out[dim] = |w|^2 after the sweep.  Returns true when w was also normalised (only if asked to).
+// fused kernel table: NCOMP x (E, DMAX)
+static const void *ilu_mgs_fn(int ncomp, int e) {
+  if (ncomp == 3) return e <= 8 ? (const void *)k_ilu_mgs<3, 2, 8, 8, 10> : e == 9 ? (const void *)k_ilu_mgs<3, 2, 8, 9, 9> : (const void *)k_ilu_mgs<3, 2, 8, 10, 8>;
+  return e <= 8 ? (const void *)k_ilu_mgs<2, 2, 8, 8, 10> : e == 9 ? (const void *)k_ilu_mgs<2, 2, 8, 9, 9> : (const void *)k_ilu_mgs<2, 2, 8, 10, 8>;
+}
+// May the triangular solves of the velocity ILU(0) and the sweep behind them run as ONE launch (k_ilu_mgs)?  One GPU, the one-exchange
+// sweep, the lane-owner stream with two entries per tick, a wave's rows within 256 x 8 or 256 x 10 entries, the grid resident.
+// Returns the entries per thread (8 / 10) or 0.
+static int ilu_mgs_entries(nsx_handle *h, Span sp, int dim, const double *gram) {
+  // Opt-in (NSX_ILU_MGS=1; read per call: the tests switch it inside one process).  Measured at the bench size: 45.7 us per launch
+  // against 26.7 + 25.7 for the two separate kernels, 3.05 against 3.18 ms per outer iteration (-4 %) -- and a re-rolled iteration
+  // history (the sweep's sums are grouped by rank block): both sampled windows of the chaotic GMRES(28) sequence came out with MORE
+  // restart steps (driver window 25.4 against 21.9 outer iterations per step, 325 steps 30.4 against 28.0), i.e. slower per time step.
+  // The default therefore stays with the separate kernels and rounds 3-4's history.
+  const bool wanted = getenv("NSX_ILU_MGS") && atoi(getenv("NSX_ILU_MGS")) == 1;
+  const IluSchedule &s = h->schedF;
+  if (!wanted || h->comm || h->mgs_disabled || !h->mgs_box.p || h->mgs_links != 0 || !gram || dim + 2 > MGS_STEPS) return 0;
+  if (sp.n != h->n_u || sp.split != sp.n || sp.gap != 0 || (h->dim != 2 && h->dim != 3)) return 0;
+  if (!s.packed_ok || s.levelled || s.stream_ncomp != h->dim || s.stream_epl != 2 || s.n_waves < 1 || s.n_waves > MGS_MAX_WG) return 0;
+  if (getenv("NSX_PF") && atoi(getenv("NSX_PF")) != 8) return 0;
+  // entries per thread x basis vectors kept in registers: 8 x 10, 9 x 9 (the bench layout: 747 rows in its largest wave), 10 x 8
+  const int entries = s.max_wave_rows * h->dim, e = entries <= 256 * 8 ? 8 : entries <= 256 * 9 ? 9 : entries <= 256 * 10 ? 10 : 0;
+  if (!e) return 0;
+  const int k = e - 8;
+  if (h->ilu_mgs_cap[k] < 0 || h->ilu_mgs_cap_rows != s.max_wave_rows) {  // resident-grid limit with this schedule's LDS request
+    if (h->ilu_mgs_cap_rows != s.max_wave_rows) h->ilu_mgs_cap[0] = h->ilu_mgs_cap[1] = h->ilu_mgs_cap[2] = -1;
+    h->ilu_mgs_cap_rows = s.max_wave_rows;
+    int cus = 0, per_cu = 0;
+    HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->prm.device));
+    const size_t shm = ilu_mgs_lds_doubles((s.max_wave_rows + 64) * h->dim, e) * sizeof(double);
+    if (shm > 80 * 1024) h->ilu_mgs_cap[k] = 0;
+    else {
+      if (shm > 64 * 1024) HIP_CHECK(hipFuncSetAttribute(ilu_mgs_fn(h->dim, e), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));  // (160 KB per CU on gfx950; the runtime's default limit per workgroup is 64 KB)
+      HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ilu_mgs_fn(h->dim, e), 256, shm));
+      h->ilu_mgs_cap[k] = std::min(MGS_MAX_WG, per_cu * cus);
+      if (getenv("NSX_MGS_MAXWG")) h->ilu_mgs_cap[k] = std::min(h->ilu_mgs_cap[k], atoi(getenv("NSX_MGS_MAXWG")));
+    }
+    if (getenv("NSX_DEBUG"))
+      fprintf(stderr, "[nsx] triangular solves + sweep in one launch (%d entries per thread, %zu B of LDS): %d resident workgroups for %d waves of the solve\n", e, shm,
+              h->ilu_mgs_cap[k], s.n_waves);
+  }
+  return s.n_waves <= h->ilu_mgs_cap[k] ? e : 0;
+}
+
 bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int slot0, bool normalize, double *out,
-           const std::function<void()> *after_launch, bool consider, double *gram) {
+           const std::function<void()> *after_launch, bool consider, double *gram, const double *ilu_rhs) {
   const int n = sp.n;
+  // ilu_rhs: w = (LU)^-1 ilu_rhs (the velocity ILU(0) of the last initialisation) comes FIRST -- inside the sweep's launch when
+  // that is possible (k_ilu_mgs), as the separate kernel otherwise
+  int fused_e = 0;
+  if (ilu_rhs) {
+    if (!h->comm) mgs_setup(h);
+    fused_e = ilu_mgs_entries(h, sp, dim, gram);
+    if (!fused_e) ilu_solve(h, h->gA, h->schedF, h->luF.p, ilu_rhs, w, h->dim, "ilu_solve_F");
+  }
   // distributed run: the persistent sweep with the collective inside its exchange (k_mgs_one<.., true>) needs stream collectives
   // (RCCL), the Gram cache and room on the device; NSX_MGS_DIST=0 keeps the two-pass sweep (mgs_lowsync)
   if (h->comm && h->mgs_dist_state < 0) {  // decided once per handle, by all ranks together (comm_streams_concurrent)
@@ -1388,7 +1839,12 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
     if (it == h->mgs_dist_fit.end()) it = h->mgs_dist_fit.emplace(role, comm_agree_all(h, e_inst != 0 && per_thread <= per_thread_max) ? 1 : 0).first;
     if (!it->second || dim + 2 > MGS_STEPS) dist = false;
   }
-  if ((h->comm && !dist) || h->mgs_max_wg == 0 || dim + 2 > MGS_STEPS || per_thread > per_thread_max || (h->mgs_links == 0 && !gram)) {
+  if (fused_e) {
+    nwg = h->schedF.n_waves;
+    e_inst = fused_e;
+    per_thread = fused_e;
+  }
+  if (!fused_e && ((h->comm && !dist) || h->mgs_max_wg == 0 || dim + 2 > MGS_STEPS || per_thread > per_thread_max || (h->mgs_links == 0 && !gram))) {
     // distributed solve: two collectives per sweep (mgs_lowsync); NSX_MGS_LOWSYNC=0: one launch + all-reduce per link, as the
     // reference's MPI run does.  Without a Gram cache (or too many vectors for it) the chain as well.
     if (h->ls_mode < 0) h->ls_mode = getenv("NSX_MGS_LOWSYNC") ? atoi(getenv("NSX_MGS_LOWSYNC")) : 2;  // read once per handle: 0 chain, 1 two collectives, 2 one
@@ -1401,11 +1857,14 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
   const unsigned long long seq = ++h->pub_seq;
   double *ext_vals_this = nullptr;  // distributed: the buffer this sweep's collective works on
   h->mgs_last_e = e_inst;
+  h->mgs_last_fused = fused_e ? 1 : 0;
+  h->mgs_fused_launches += fused_e ? 1 : 0;
   h->mgs_last_nwg = nwg;
   h->mgs_last_dist = dist ? 1 : 0;
   h->mgs_max_e_seen = std::max(h->mgs_max_e_seen, e_inst);
   {
-    LaunchScope ls(h, "mgs_sweep", 8.0 * n * (dim + 2));
+    LaunchScope ls(h, fused_e ? "ilu_mgs" : "mgs_sweep",
+                   8.0 * n * (dim + 2) + (fused_e ? 12.0 * (double)h->schedF.in_block_nnz + (double)h->N2 * (4 + 8.0 * h->dim) - 8.0 * n : 0.0));
     MgsArgs V;
     for (int i = 0; i < dim; ++i) V.v[i] = vs[i];
     for (int i = dim; i < MGS_STEPS; ++i) V.v[i] = nullptr;
@@ -1425,8 +1884,54 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
     // beyond that — /opt/skills/guides/MI355X_MICROARCH.md, "Residency and cooperative launch" — and was removed.)  What makes the
     // sweep safe is the bounded wait: should a workgroup be missing (another stream or process holds compute units), the kernel
     // ends without writing w and the sweep is redone by the launch-per-link chain below.
-    const void *fn = dist ? mgs_one_fn(e_inst, true) : mgs_fn(M, e_inst);
-    if (M == 0) {
+    const void *fn = fused_e ? ilu_mgs_fn(h->dim, fused_e) : dist ? mgs_one_fn(e_inst, true) : mgs_fn(M, e_inst);
+    if (fused_e) {
+      const IluSchedule &s_ = h->schedF;
+      int reset_words = reset_wg * reset_steps;
+      double *gram_ = gram;
+      double guard_ = mgs_norm_guard(h);
+      IluMgsArgs I{s_.pk_row_ptr.p, s_.pk_rows.p, s_.pk_slab_ptr.p, reinterpret_cast<const uint32_t *>(s_.pk_meta.p), s_.pk_val.p, s_.pk_dinv.p, ilu_rhs,
+                   (s_.max_wave_rows + 64) * h->dim, (getenv("NSX_ILU_MGS_SPLIT") && atoi(getenv("NSX_ILU_MGS_SPLIT")) == 0) ? 0 : 1, nullptr,
+                   getenv("NSX_ILU_MGS_PRE") ? atoi(getenv("NSX_ILU_MGS_PRE")) : 0, getenv("NSX_ILU_MGS_STAGE") ? atoi(getenv("NSX_ILU_MGS_STAGE")) : 0};
+      // development (tools/r05_ilu_mgs_trace.sh): wall-clock stamps of every wave of ONE launch (the NSX_ILU_MGS_TRACE_CALL-th, default 3000)
+      DevBuf<unsigned long long> trace_buf;
+      const char *trace_path = getenv("NSX_ILU_MGS_TRACE");
+      const bool traced = trace_path && h->mgs_fused_launches == (getenv("NSX_ILU_MGS_TRACE_CALL") ? atoi(getenv("NSX_ILU_MGS_TRACE_CALL")) : 3000);
+      if (traced) {
+        trace_buf.alloc((size_t)nwg * 4 * 16);
+        trace_buf.zero(h->stream);
+        I.trace = trace_buf.p;
+      }
+      const size_t shm = ilu_mgs_lds_doubles(I.ilu_doubles, fused_e) * sizeof(double);
+      void *args[] = {&n_, &w, &V, &dim_, &gram_, &box, &box_next, &reset_words, &sout, &err, &tail, &norm_, &consider_, &pub_vals, &pub_flag, &seq_, &drop_wg, &guard_, &I};
+      HIP_CHECK(hipLaunchKernel(fn, dim3(nwg), dim3(256), args, shm, h->stream));
+      if (traced) {
+        std::vector<unsigned long long> tr((size_t)nwg * 4 * 16);
+        trace_buf.download(tr.data(), tr.size(), h->stream);
+        if (FILE *f = fopen(trace_path, "w")) {
+          fprintf(f, "# k_ilu_mgs launch %d: dim %d, %d workgroups, %d entries per thread; per wave: workgroup wave rows, then stamps 0..8 in ticks of 10 ns relative to the grid's first stamp\n"
+                     "# 0 start, 1 rhs rows in LDS, 2 forward sweep done, 3 backward sweep done (sweeping wave only), 4 basis entries arrived, 5 z complete (barrier), 6 local sums, 7 totals picked up, 8 update done\n",
+                  h->mgs_fused_launches, dim, nwg, fused_e);
+          unsigned long long t0 = ~0ull;
+          for (size_t q = 0; q < tr.size(); q += 16)
+            if (tr[q]) t0 = std::min(t0, tr[q]);
+          std::vector<int32_t> rp((size_t)nwg + 1);
+          s_.pk_row_ptr.download(rp.data(), rp.size(), h->stream);
+          for (int b = 0; b < nwg; ++b)
+            for (int wv_ = 0; wv_ < 4; ++wv_) {
+              fprintf(f, "%d %d %d", b, wv_, rp[b + 1] - rp[b]);
+              for (int k = 0; k < 9; ++k) {
+                const unsigned long long v = tr[((size_t)b * 4 + wv_) * 16 + k];
+                fprintf(f, " %lld", v ? (long long)(v - t0) : -1ll);
+              }
+              fprintf(f, "\n");
+            }
+          fclose(f);
+        }
+      }
+      h->mgs_used_wg[h->mgs_parity] = 1;
+      h->mgs_used_steps[h->mgs_parity] = (2 * dim + 2) * nwg;
+    } else if (M == 0) {
       // k_mgs_one: mailboxes box[v * nwg + wg] for the 2 dim + 1 values of the single exchange (+ 1 for the explicit norm)
       int reset_words = reset_wg * reset_steps;
       double *gram_ = gram;
@@ -1542,6 +2047,7 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
       if (h->ls_mode && dim <= 31) mgs_lowsync(h, sp, w, dim, vs, slot0, out, consider, gram);
       else mgs_chain(h, sp, w, dim, vs, slot0, out, consider);
     } else {
+      if (fused_e) ilu_solve(h, h->gA, h->schedF, h->luF.p, ilu_rhs, w, h->dim, "ilu_solve_F");  // the fused launch ended without writing w: z first, then the chain
       mgs_chain(h, sp, w, dim, vs, slot0, out, consider);
     }
     if (ran_ahead) h->mgs_redo_ahead = true;
@@ -1776,9 +2282,9 @@ extern "C" int nsx_persistent_state(nsx_handle *h, int state[4]) {
 }
 
 // Which code paths this handle's products and solves take (tests, bench.py's rehearsal log): see include/nsx.h
-extern "C" int nsx_path_info(nsx_handle *h, int info[24]) {
+extern "C" int nsx_path_info(nsx_handle *h, int info[32]) {
   if (!h || !info) return NSX_ERR_ARG;
-  for (int k = 0; k < 24; ++k) info[k] = 0;
+  for (int k = 0; k < 32; ++k) info[k] = 0;
   if (!h->have_mesh) return NSX_OK;
   try {
     HIP_CHECK(hipSetDevice(h->prm.device));
@@ -1822,6 +2328,8 @@ extern "C" int nsx_path_info(nsx_handle *h, int info[24]) {
     info[20] = nsx::cdiv(std::max(1, h->schedS.n_blocks), 1024);  // Schur blocks per entry of a partial-sum array of the two-launch CG (1: no fold launch)
     info[22] = h->N2;
     info[23] = h->NP;
+    info[24] = h->mgs_last_fused;
+    info[25] = h->mgs_fused_launches;
   } catch (const nsx::Error &e) {
     h->err = e.msg;
     return e.code;

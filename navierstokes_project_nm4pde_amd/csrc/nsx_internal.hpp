@@ -316,6 +316,8 @@ struct nsx_handle {
   bool cu_reserve_failed = false;    // the ranks tried to mask their streams and one of them could not: all are back on plain streams, nobody asks again
   bool mgs_leave_req = false;        // a flag wait of this rank's grid timed out on its own: the next sweep asks all ranks to leave the persistent path
   int mgs_local_timeouts = 0;
+  int mgs_last_fused = 0, mgs_fused_launches = 0;  // the last persistent sweep had the velocity triangular solves inside (k_ilu_mgs)
+  int ilu_mgs_cap[3] = {-1, -1, -1}, ilu_mgs_cap_rows = -1;  // resident-grid limits of the fused kernel's two instantiations (for the LDS request of the current schedule)
   int mgs_last_e = 0, mgs_last_nwg = 0, mgs_last_dist = 0, mgs_max_e_seen = 0;  // the last persistent sweep: entries per thread, grid, collective inside (nsx_path_info)
   int cgd_agreed = -1;               // two-launch Schur CG: -1 not decided for the current schedules, 0 / 1 the ranks' common answer
   nsx::DevBuf<double> ext_self;           // development (NSX_EXT_SELF_P2P): operands of the self-addressed send / receive in front of the sweep's collective
@@ -460,7 +462,8 @@ void v_add_and_dot(nsx_handle *h, Span n, double *d, double a, int aslot, const 
 // after_launch (optional) runs between the launch and the wait for the coefficients, only when the sweep is one launch
 // AND normalises w: the caller may enqueue work that depends on the finished w alone.
 bool v_mgs(nsx_handle *h, Span n, double *w, int dim, double *const *vs, int slot0, bool normalize, double *out,
-           const std::function<void()> *after_launch = nullptr, bool consider = false, double *gram = nullptr);
+           const std::function<void()> *after_launch = nullptr, bool consider = false, double *gram = nullptr, const double *ilu_rhs = nullptr);
+// ilu_rhs: the sweep's input is w = (LU_F)^-1 ilu_rhs, computed first (inside the sweep's own launch where possible: k_ilu_mgs)
 // consider: also out[dim+1] = |w|^2 BEFORE the sweep (SolverGMRES' re-orthogonalisation test); a single-launch sweep then
 // normalises w only if the test does not ask for a second sweep.
 void v_axpy_multi(nsx_handle *h, Span n, double *x, int k, double *const *vs, const double *coef_host);

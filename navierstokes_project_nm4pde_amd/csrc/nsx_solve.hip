@@ -95,8 +95,11 @@ enum { S_H = 8 /* 8..8+N_TMP */, S_NRM = 40, S_H2 = 41 /* re-orthogonalisation c
 // preconditioner of the next iteration are then enqueued behind the Gram-Schmidt sweep, before its coefficients are waited for.
 // (Fusing the two into one launch per rank block — four waves for the block's rows of A x, then one wave for the sweeps — was
 // tried: 100 us against 35 + 35, the workgroups of the product hold LDS and registers the sweeping waves of other blocks need.)
+// P_is_ilu_F: P is the velocity ILU(0) of the last initialisation (the inner solves on F): its triangular solves then run INSIDE the
+// launch of the sweep that follows them (v_mgs with ilu_rhs, k_ilu_mgs) where the layout allows it -- the preconditioned vector never
+// travels through memory between the two; only the operator of the next iteration is enqueued ahead.
 static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b, const Op &P, Span n, int len, double tol, int maxiter,
-                         bool zero_new = false, bool x_is_zero = false, bool plain_P = false) {
+                         bool zero_new = false, bool x_is_zero = false, bool plain_P = false, bool P_is_ilu_F = false) {
   SolveResult res{1, 0, 0.0};
   std::vector<std::unique_ptr<Tmp>> tmp(N_TMP);
   auto vec = [&](int i) -> double * {
@@ -122,6 +125,9 @@ static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b,
     }
     gram = h->ls_gram.p + (size_t)depth.d * 1024;
   }
+  // (in place needs the lane-owner stream: its kernel loads the right-hand side rows into LDS before it writes anything)
+  const bool ilu_conv = P_is_ilu_F && !h->comm && h->schedF.packed_ok && !h->schedF.levelled && h->schedF.stream_ncomp == h->dim &&
+                        (getenv("NSX_ILU_MGS") && atoi(getenv("NSX_ILU_MGS")) == 1);  // opt-in: see ilu_mgs_entries (nsx_blas.hip)
   double H[N_TMP][N_TMP - 1];
   double gamma[N_TMP], ci[N_TMP - 1], si[N_TMP - 1], hh[N_TMP + 2], h2[N_TMP + 2];
   int accumulated = 0, state = 0, dim = 0;
@@ -157,7 +163,16 @@ static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b,
         A(p, src);
         P(dst, p);
       };
-      if (ahead == 0) apply_AP(vv, vec(inner));
+      // ilu_conv: the product A v lands in vv itself and the preconditioner is applied IN PLACE -- by the sweep's own launch (fuse) or,
+      // in a re-orthogonalisation cycle, by the separate kernel through p
+      const bool fuse = ilu_conv && !re_orth;
+      if (ilu_conv) {
+        if (ahead == 0) A(vv, vec(inner));
+        if (!fuse) {
+          v_copy(h, n.n, p, vv);
+          P(vv, p);
+        }
+      } else if (ahead == 0) apply_AP(vv, vec(inner));
       else if (ahead == 1) P(vv, p);
       ahead = 0;
       dim = inner + 1;
@@ -177,7 +192,10 @@ static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b,
       const std::function<void()> next_A = [&]() {
         if (inner + 1 < N_TMP - 2 && !likely_last) {
           static const int ahead_mode = getenv("NSX_AHEAD_MODE") ? atoi(getenv("NSX_AHEAD_MODE")) : 2;
-          if (plain_P && ahead_mode == 2) {  // inner solves on F: operator AND preconditioner of the next iteration are plain kernels that depend on vv alone
+          if (ilu_conv) {  // the next iteration's product goes straight into its own vector; its preconditioner runs inside the next sweep's launch
+            A(vec(inner + 2), vv);
+            ahead = 1;
+          } else if (plain_P && ahead_mode == 2) {  // operator AND preconditioner of the next iteration are plain kernels that depend on vv alone
             apply_AP(vec(inner + 2), vv);
             ahead = 2;
           } else {   // the outer solve's preconditioner runs Krylov solves of its own (host round trips, the same scalar slots): only A
@@ -186,7 +204,7 @@ static SolveResult gmres(nsx_handle *h, const Op &A, double *x, const double *b,
           }
         }
       };
-      bool normalized = v_mgs(h, n, vv, dim, basis, S_H, !re_orth, hh, &next_A, consider, gram);
+      bool normalized = v_mgs(h, n, vv, dim, basis, S_H, !re_orth, hh, &next_A, consider, gram, fuse ? vv : nullptr);
       if (h->mgs_redo_ahead) {  // the sweep fell back to the launch-per-link chain: A * vv was enqueued on an unfinished vv
         h->mgs_redo_ahead = false;
         ahead = 0;
@@ -431,7 +449,7 @@ void prec_vmult(nsx_handle *h, int type, double tol, int maxit, double *dst, con
     Tmp yu(h, len_u), yp(h, len_p), tmp(h, len_p), tmp2(h, len_u), res(h, len_u);
     v_copy(h, n_u, yu.p(), src_u);                                                            // :375
     v_copy(h, n_p, yp.p(), src_p);                                                            // :376
-    count(st, true, gmres(h, Fm, yu.p(), src_u, PF, n_u, len_u, tol * norm2(h, n_u, src_u), maxit, false, false, true)); // :371-382
+    count(st, true, gmres(h, Fm, yu.p(), src_u, PF, n_u, len_u, tol * norm2(h, n_u, src_u), maxit, false, false, true, true)); // :371-382
     spmv_B(h, yu.p(), tmp.p());                                                               // :385
     v_add(h, n_p, tmp.p(), -1.0, src_p);                                                      // :386
     count(st, false, cg_S(yp.p(), tmp.p()));                                                  // :388-390
@@ -439,13 +457,13 @@ void prec_vmult(nsx_handle *h, int type, double tol, int maxit, double *dst, con
     spmv_G(h, dst_p, tmp2.p(), false);                                                        // :398
     v_zero(h, n_u, res.p());                                                                  // :401
     v_copy(h, n_u, dst_u, yu.p());                                                            // :402
-    count(st, true, gmres(h, Fm, res.p(), tmp2.p(), PF, n_u, len_u, tol * norm2(h, n_u, tmp2.p()), maxit, false, true, true));  // :403-405
+    count(st, true, gmres(h, Fm, res.p(), tmp2.p(), PF, n_u, len_u, tol * norm2(h, n_u, tmp2.p()), maxit, false, true, true, true));  // :403-405
     v_sadd(h, n_u, dst_u, -1., 1., res.p());  // dst.block(0).sadd(-1,res): dst = -dst + res            :406
   } else if (type == NSX_PREC_SIMPLE) {  // Prec.hpp:151-205
     Tmp sol1_u(h, len_u), sol1_p(h, len_p), temp_1(h, len_p), tmp(h, len_u);
     v_copy(h, n_u, sol1_u.p(), src_u);                                                             // :168
     v_copy(h, n_p, sol1_p.p(), src_p);                                                             // :169
-    count(st, true, gmres(h, Fm, sol1_u.p(), src_u, PF, n_u, len_u, tol * norm2(h, n_u, src_u), maxit, false, false, true));  // :157-173
+    count(st, true, gmres(h, Fm, sol1_u.p(), src_u, PF, n_u, len_u, tol * norm2(h, n_u, src_u), maxit, false, false, true, true));  // :157-173
     spmv_B(h, sol1_u.p(), temp_1.p());                                                             // :175
     v_add(h, n_p, temp_1.p(), -1.0, src_p);                                                        // :176
     count(st, false, cg_S(sol1_p.p(), temp_1.p()));                                               // :179-182
@@ -457,7 +475,7 @@ void prec_vmult(nsx_handle *h, int type, double tol, int maxit, double *dst, con
     v_add(h, n_u, dst_u, -1.0, tmp.p());                                                           // :203
   } else if (type == NSX_PREC_ASIMPLE) {  // Prec.hpp:254-311 (dst is the caller's vector: its content is the initial guess)
     Tmp tmp_u(h, len_u), tmp_p(h, len_p);
-    count(st, true, gmres(h, Fm, dst_u, src_u, PF, n_u, len_u, tol * norm2(h, n_u, src_u), maxit, false, false, true));  // :271-273
+    count(st, true, gmres(h, Fm, dst_u, src_u, PF, n_u, len_u, tol * norm2(h, n_u, src_u), maxit, false, false, true, true));  // :271-273
     spmv_B(h, dst_u, dst_p);                                                                   // :280
     v_sadd(h, n_p, dst_p, -1.0, 1.0, src_p);                                                   // :281
     v_copy(h, n_p, tmp_p.p(), dst_p);                                                          // :282

@@ -208,12 +208,12 @@ class Nsx:
     PATH_KEYS = ("spmv_lds_staged", "spmv_chunks", "spmv_chunks_behind_halo", "sweep_entries_per_thread", "sweep_grid", "sweep_collective_inside",
                  "sweep_entries_per_thread_max", "cus_reserved", "schur_cg_path", "schur_blocks", "neighbours", "nodes_sent_per_exchange", "ghost_nodes",
                  "schur_dense_inverses", "sweep_off", "fallbacks", "rccl_sweep_velocity_plain", "rccl_sweep_velocity_masked", "rccl_sweep_block_plain",
-                 "rccl_sweep_block_masked", "schur_blocks_per_partial", "sweep_velocity_one_gpu", "owned_p2_nodes", "owned_p1_nodes")
+                 "rccl_sweep_block_masked", "schur_blocks_per_partial", "sweep_velocity_one_gpu", "owned_p2_nodes", "owned_p1_nodes", "sweep_with_ilu_inside", "fused_launches")
 
     def path_info(self):
         """dict: which code paths the handle's products and solves take (nsx_path_info; schur_cg_path: 1 launch per operation,
         2 persistent, 3 two launches per iteration)"""
-        v = (C.c_int * 24)()
+        v = (C.c_int * 32)()
         self._ck(self.L.nsx_path_info(self._h, v))
         return {k: int(v[i]) for i, k in enumerate(self.PATH_KEYS)}
 
