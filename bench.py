@@ -53,10 +53,10 @@ else:
     _BIG_SCHEDULE = None
 BIG_STEPS, BIG_WARMUP, BIG_SPINUP = _BIG_SCHEDULE or (6, 1, 3)  # schedule of the strong_10M leg: the same on one GPU (committed base) and on N (short: at N = 2 a step of
                                              # this mesh still takes seconds, and the whole invocation has to stay within minutes)
-PMC_PROFILE = "profiles/r04_pmc_fetch_write_per_kernel.json"
+PMC_PROFILE = "profiles/r05_pmc_fetch_write_per_kernel.json"
 LAYOUT_PROFILE = "profiles/r04_layout_iterations.json"
 BIG_BASE_PROFILE = "profiles/r05_strong_10M_one_gpu.json"
-STEP_HISTORY = "profiles/r04_step_history.txt"
+STEP_HISTORY = "profiles/r05_step_history.txt"
 NU, DT = 1e-3, 2e-4
 
 # scope name used by the library's HIP-event timer -> kernel symbol in rocprofv3 output
@@ -141,7 +141,7 @@ def pmc_traffic(scope, live=None):
             return of(live), "live"
         except KeyError:
             pass
-    for rel in (PMC_PROFILE, "profiles/r03_pmc_fetch_write_per_kernel.json"):
+    for rel in (PMC_PROFILE, "profiles/r04_pmc_fetch_write_per_kernel.json"):
         try:
             with open(os.path.join(ROOT, rel)) as f:
                 return of(json.load(f)), rel

@@ -34,7 +34,7 @@ def test_kernels_named_in_bench_exist_in_the_committed_profiles():
     b = _bench()
     with open(os.path.join(ROOT, b.PMC_PROFILE)) as f:
         pmc = json.load(f)
-    with open(os.path.join(ROOT, "profiles", "r04_kernel_stats_bench_steps5.csv")) as f:
+    with open(os.path.join(ROOT, "profiles", "r05_kernel_stats_bench_steps5.csv")) as f:
         stats = [r["Name"] for r in csv.DictReader(f)]
     for scope in ("spmv_F", "ilu_solve_F", "mgs_sweep", "cg_S"):
         name = b.KERNEL_OF[scope]
@@ -45,7 +45,7 @@ def test_kernels_named_in_bench_exist_in_the_committed_profiles():
 
 
 def test_committed_bench_line_carries_the_contract_fields():
-    with open(os.path.join(ROOT, "profiles", "r04_bench.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r05_bench.json")) as f:
         d = json.loads(f.read().strip().splitlines()[-1])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
                 "roofline", "cpu_baseline"):
