@@ -507,7 +507,7 @@ void abs_rowsum(nsx_handle *h, const DevCsr &g, const double *vals, double *d) {
 // block(0,1) = -block(1,0)^T with the Dirichlet rows cleared (NS3D.cpp:258,261 + apply_boundary_values), so
 //   S_ij = sum_{k in row_i(B) ^ row_j(B)} sum_c B[i,k][c] * w[k][c] * B[j,k][c],   w = -v * dirichlet_mask.
 // One wave per row i: row i (columns + dim weighted values) is staged in LDS, each lane takes one S entry (i,j),
-// walks row j of B and binary-searches its columns in the LDS copy.
+// walks row j of B and merges its (sorted) columns with the LDS copy.
 template <int DIM>
 __global__ __launch_bounds__(64) void k_schur(int n_rows, const int32_t *__restrict__ srp, const int32_t *__restrict__ sci,
                                               const int32_t *__restrict__ brp, const int32_t *__restrict__ bci,
@@ -529,16 +529,20 @@ __global__ __launch_bounds__(64) void k_schur(int n_rows, const int32_t *__restr
   for (int e = srp[i] + threadIdx.x; e < srp[i + 1]; e += 64) {
     const int j = sci[e];
     double acc = 0.0;
+    // both rows are sorted by column: one pass over row j with a cursor into row i's LDS copy (round 5; a binary search per entry of
+    // row j before: 1.24 ms per step).  The products enter the sum in row j's order as before: bit-identical.
+    // both rows are sorted by column: one pass over row j with a cursor into row i's LDS copy (round 5; a binary search per entry of
+    // row j before: 1.24 ms per step, now 0.93).  The products enter the sum in row j's order as before: bit-identical.  What bounds it
+    // now is the gather rate: every lane walks another row j, so a load instruction touches 64 different sectors (430 M lane-loads per
+    // product); fetching eight entries per trip changed nothing (1.02 ms).  A wave per (i, j) pair would read row j coalesced, but
+    // its sum would need the lanes' products in row order -- another rounding, another iteration history.
+    int q = 0;
     for (int p = brp[j]; p < brp[j + 1]; ++p) {
       const int k = bci[p];
-      int lo = 0, hi = nb - 1, pos = -1;
-      while (lo <= hi) {
-        const int mid = (lo + hi) >> 1, cm = rc[mid];
-        if (cm < k) lo = mid + 1; else if (cm > k) hi = mid - 1; else { pos = mid; break; }
-      }
-      if (pos >= 0) {
+      while (q < nb && rc[q] < k) ++q;
+      if (q < nb && rc[q] == k) {
 #pragma unroll
-        for (int c = 0; c < DIM; ++c) acc += rv[pos * DIM + c] * bv[(size_t)p * DIM + c];
+        for (int c = 0; c < DIM; ++c) acc += rv[q * DIM + c] * bv[(size_t)p * DIM + c];
       }
     }
     sv[e] = acc;
@@ -638,6 +642,45 @@ __global__ __launch_bounds__(ILU_WAVES * 64) void k_ilu_factor(const int32_t *__
 // Thread j owns column j: forward sweep Y e_j = L^-1 e_j row by row, then the backward sweep in place.  Columns are
 // independent, so there is no synchronisation; for a fixed row all threads read the same factor entries (broadcast)
 // and consecutive entries of a row of P (coalesced).
+// The same with the block's matrix in LDS while it is built (round 5): a thread owns a column and walks the rows; every row reads
+// entries of its column that the same thread wrote a few rows earlier -- through global memory that is a store -> load round trip
+// through L2 per row (0.76 ms per step for 511 blocks of <= 96 rows), through LDS a few hundred cycles.  Same operations on the same
+// operands in the same order: bit-identical (tests/test_gpu_errors.py).
+__global__ __launch_bounds__(128) void k_ilu_invert_lds(const int32_t *__restrict__ bptr, const int64_t *__restrict__ off,
+                                                        const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                        const int32_t *__restrict__ diag, const double *__restrict__ lu, double *__restrict__ P) {
+  extern __shared__ double Ps[];  // [n][n] row-major: column j of all rows by thread j, consecutive threads on consecutive banks
+  __shared__ int s_rp[113], s_dg[112];  // the rows' entry ranges and diagonal positions: one trip for the block instead of one per row
+  const int blk = blockIdx.x, r0 = bptr[blk], n = bptr[blk + 1] - r0;
+  const int j = threadIdx.x;
+  for (int t = threadIdx.x; t <= n; t += 128) s_rp[t] = rp[r0 + t];
+  for (int t = threadIdx.x; t < n; t += 128) s_dg[t] = diag[r0 + t];
+  __syncthreads();
+  if (j < n) {
+    for (int i = 0; i < n; ++i) {  // Y = L^-1 (unit lower)
+      const int pe = s_dg[i];
+      double acc = i == j ? 1.0 : 0.0;
+      for (int p = s_rp[i]; p < pe; ++p) {
+        const int k = ci[p] - r0;
+        if (k >= 0) acc -= lu[p] * Ps[k * n + j];
+      }
+      Ps[i * n + j] = acc;
+    }
+    for (int i = n - 1; i >= 0; --i) {  // P = U^-1 (D^-1 Y), in place from the last row up
+      const int pd = s_dg[i], pe = s_rp[i + 1];
+      double acc = lu[pd] * Ps[i * n + j];
+      for (int p = pd + 1; p < pe; ++p) {
+        const int k = ci[p] - r0;
+        if (k < n) acc -= lu[p] * Ps[k * n + j];
+      }
+      Ps[i * n + j] = acc;
+    }
+  }
+  __syncthreads();
+  double *Pb = P + off[blk];
+  for (int q = threadIdx.x; q < n * n; q += 128) Pb[q] = Ps[q];
+}
+
 __global__ __launch_bounds__(256) void k_ilu_invert(const int32_t *__restrict__ bptr, const int64_t *__restrict__ off,
                                                     const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
                                                     const int32_t *__restrict__ diag, const double *__restrict__ lu, double *P) {
@@ -1053,8 +1096,20 @@ void ilu_factor(nsx_handle *h, const DevCsr &g, IluSchedule &s, const double *va
   }
   if (s.dense) {
     LaunchScope ls(h, "ilu_invert", 8.0 * (double)s.dn_entries + 12.0 * g.nnz());
-    hipLaunchKernelGGL(k_ilu_invert, dim3(s.n_blocks), dim3(256), 0, h->stream, s.block_ptr.p, s.dn_off.p, g.rowptr.p, g.colind.p, g.diag.p, lu,
-                       s.dn_P.p);
+    // blocks of up to 112 rows (98 KB of LDS: one workgroup per CU and half) keep the n x n matrix in LDS while it is built
+    const bool inv_lds = !(getenv("NSX_ILU_INVERT_LDS") && atoi(getenv("NSX_ILU_INVERT_LDS")) == 0);  // read per call: the tests switch it inside one process
+    const size_t shm = (size_t)s.max_rows * s.max_rows * sizeof(double);
+    if (inv_lds && s.max_rows <= 112) {
+      static bool attr_set = false;
+      if (!attr_set && shm > 64 * 1024) {
+        HIP_CHECK(hipFuncSetAttribute((const void *)k_ilu_invert_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 112 * (int)sizeof(double)));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(k_ilu_invert_lds, dim3(s.n_blocks), dim3(128), shm, h->stream, s.block_ptr.p, s.dn_off.p, g.rowptr.p, g.colind.p, g.diag.p, lu, s.dn_P.p);
+    } else {
+      hipLaunchKernelGGL(k_ilu_invert, dim3(s.n_blocks), dim3(256), 0, h->stream, s.block_ptr.p, s.dn_off.p, g.rowptr.p, g.colind.p, g.diag.p, lu,
+                         s.dn_P.p);
+    }
   }
 }
 

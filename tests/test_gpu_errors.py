@@ -539,3 +539,32 @@ def test_triangular_solves_inside_the_sweeps_launch_equal_the_separate_kernels(d
         for key in ("outer_iterations", "inner_F_iterations", "inner_S_iterations"):
             assert abs(a[key] - b[key]) <= max(1, 0.02 * a[key]), key
     assert np.abs(x0 - x1).max() < 1e-9 * np.abs(x0).max()
+
+
+def test_block_inverses_built_in_lds_are_bit_identical_to_the_ones_built_through_global_memory():
+    """k_ilu_invert_lds keeps a Schur ILU block's n x n inverse in LDS while a thread per column walks the rows (NSX_ILU_INVERT_LDS=0:
+    k_ilu_invert, the same walk through global memory).  Same operations in the same order: the application of the factors
+    (ilu_apply on the Schur matrix = one dense product per block) and a whole time step agree to the last bit."""
+    import navierstokes_project_nm4pde_amd.nsx as nsx
+    from navierstokes_project_nm4pde_amd.frontend import merge_ranks
+    p = Problem("cylinder", 3, 3, n_sub=128, ordering="colour")
+    res = []
+    for flag in ("1", "0"):
+        os.environ["NSX_ILU_INVERT_LDS"] = flag
+        try:
+            dev = p.device()
+            dev.set_schur_blocks(merge_ranks(p.dofs.owned_p_ptr, 96))
+            dev.set_solution(p.smooth_velocity())
+            dev.assemble(nsx.TEMAM)
+            dev.apply_boundary_values(*_bc(p, p.deltat))
+            dev.prec_initialize(0)
+            b = np.random.default_rng(2).standard_normal(p.dofs.n_p)
+            z = dev.ilu_apply(1, b)
+            st = dev.solve_time_step(0)
+            res.append((z, dev.solution_owned.copy(), st, dev.schur().data.copy()))
+            dev.close()
+        finally:
+            os.environ.pop("NSX_ILU_INVERT_LDS", None)
+    (z0, x0, s0, v0), (z1, x1, s1, v1) = res
+    assert np.abs(z0).max() > 0 and np.array_equal(z0, z1) and np.array_equal(x0, x1) and np.array_equal(v0, v1)
+    assert s0["outer_iterations"] == s1["outer_iterations"] and s0["inner_S_iterations"] == s1["inner_S_iterations"]
