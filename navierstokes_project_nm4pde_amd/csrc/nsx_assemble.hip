@@ -378,6 +378,8 @@ void run_dirichlet(nsx_handle *h, int n_in, const int32_t *dofs_in, const double
   // the map uses global dofs; a rank applies the entries it owns (MatrixTools::apply_boundary_values does the same per rank)
   std::vector<int32_t> dofs;
   std::vector<double> vals;
+  dofs.reserve((size_t)std::max(0, n_in));
+  vals.reserve((size_t)std::max(0, n_in));
   const int32_t lo = dim * h->goff_u, hi = lo + h->n_u;
   for (int k = 0; k < n_in; ++k) {
     if (dofs_in[k] < 0 || dofs_in[k] >= h->n_u_glob) NSX_THROW(NSX_ERR_UNSUPPORTED, "only velocity dofs can be constrained (dof %d)", dofs_in[k]);

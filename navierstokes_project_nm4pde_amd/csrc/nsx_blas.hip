@@ -1037,13 +1037,8 @@ struct IluMgsArgs {
   const uint32_t *meta;
   const double *val, *dinv, *rhs;
   int ilu_doubles;  // LDS doubles reserved for the solve's rows (+ 64 scratch rows), the sweep's arrays follow
-  int split_simd;   // 1: the sweeping wave of the second half of the grid is wave 2 (see the kernel)
   unsigned long long *trace;  // development (NSX_ILU_MGS_TRACE): 16 wall-clock stamps per wave, or null
-  int pre_sleep, stage_sleep;  // units of ~0.5 us the non-sweeping waves wait before their first request / between two basis vectors (NSX_ILU_MGS_PRE, _STAGE)
 };
-__device__ __forceinline__ void im_sleep(int units) {
-  for (int q = 0; q < units; ++q) __builtin_amdgcn_s_sleep(16);  // 16 x 64 cycles ~ 0.5 us at 2.1 GHz
-}
 #define IM_STAMP(k)                                                                                                   \
   do {                                                                                                                \
     if (I.trace && lane == 0) I.trace[((size_t)wg * 4 + wave) * 16 + (k)] = wall_clock64();                             \
@@ -1104,10 +1099,9 @@ __global__ __launch_bounds__(256) void k_ilu_mgs(int n, double *__restrict__ w, 
   }
   __syncthreads();
   IM_STAMP(1);  // right-hand side rows in LDS
-  // which wave sweeps: the two workgroups a CU holds (b and b + nwg / 2 under the dispatcher's round-robin) put their sweeping waves on
-  // different SIMDs (a wave's SIMD is its number in the workgroup): a tick is a chain of dependent LDS trips, two of them on one SIMD
-  // take turns at its issue port
-  const int iw = (I.split_simd && 2 * wg >= nwg) ? 2 : 0;
+  // which wave sweeps.  (Giving the two workgroups of a CU different sweeping waves -- different SIMDs -- measured nothing; neither did
+  // delaying the other waves' basis requests by 4 - 12 us or pacing them one vector per 0.5 - 1 us: 45.9 - 46.8 us per launch throughout.)
+  constexpr int iw = 0;
   if (wave == iw) {  // the two sweeps of the triangular solve, exactly k_ilu_solve_lanes'
     const uint32_t scratch = (uint32_t)(nr + lane) * (8u * NCOMP);
     LaneSlot<EI> A[PF];
@@ -1141,16 +1135,11 @@ __global__ __launch_bounds__(256) void k_ilu_mgs(int n, double *__restrict__ w, 
   double wv[E], vb[DMAX][E];
   const int j_keep = dim > DMAX ? dim - DMAX : 0;
   if (wave != iw) {
-    im_sleep(I.pre_sleep);
 #pragma unroll
     for (int i = 0; i < DMAX; ++i) {
       const double *__restrict__ vp = j_keep + i < dim ? V.v[j_keep + i] : nullptr;
 #pragma unroll
       for (int k = 0; k < E; ++k) vb[i][k] = (vp && idx[k] >= 0) ? ld_stream<1>(vp + idx[k]) : 0.0;
-      if (I.stage_sleep) {
-        asm volatile("" ::: "memory");
-        im_sleep(I.stage_sleep);
-      }
     }
     constexpr int HB = (64 * E + 191) / 192;
     const int hid = (wave < iw ? wave : wave - 1) * 64 + lane;  // 0 .. 191
@@ -1891,8 +1880,7 @@ bool v_mgs(nsx_handle *h, Span sp, double *w, int dim, double *const *vs, int sl
       double *gram_ = gram;
       double guard_ = mgs_norm_guard(h);
       IluMgsArgs I{s_.pk_row_ptr.p, s_.pk_rows.p, s_.pk_slab_ptr.p, reinterpret_cast<const uint32_t *>(s_.pk_meta.p), s_.pk_val.p, s_.pk_dinv.p, ilu_rhs,
-                   (s_.max_wave_rows + 64) * h->dim, (getenv("NSX_ILU_MGS_SPLIT") && atoi(getenv("NSX_ILU_MGS_SPLIT")) == 0) ? 0 : 1, nullptr,
-                   getenv("NSX_ILU_MGS_PRE") ? atoi(getenv("NSX_ILU_MGS_PRE")) : 0, getenv("NSX_ILU_MGS_STAGE") ? atoi(getenv("NSX_ILU_MGS_STAGE")) : 0};
+                   (s_.max_wave_rows + 64) * h->dim, nullptr};
       // development (tools/r05_ilu_mgs_trace.sh): wall-clock stamps of every wave of ONE launch (the NSX_ILU_MGS_TRACE_CALL-th, default 3000)
       DevBuf<unsigned long long> trace_buf;
       const char *trace_path = getenv("NSX_ILU_MGS_TRACE");
