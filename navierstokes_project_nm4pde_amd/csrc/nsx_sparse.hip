@@ -350,7 +350,11 @@ static double bytes_halo(const HaloPlan &p, int ncomp) {
 void spmv_F(nsx_handle *h, const double *vals, const double *x, double *y) {
   if (h->dist) {
     // Scopes: "spmv_F" = the rows that need no ghost (they run while the exchange is in flight), "spmv_F_if" = the rows behind it,
-    // "halo_u_wait" = what the compute stream waits for the exchange once the first launch is through (its exposed part)
+    // "halo_u_wait" = what the compute stream waits for the exchange once the first launch is through (its exposed part).
+    // (Round 5 tried the second launch on a SECOND compute stream behind the exchange's event, beside the first launch -- a launch of a few
+    // hundred chunks costs a 12 - 18 us floor whatever it holds -- and measured it without an exchange in between, one rank's share alone
+    // on the card: 1.09 M DoF / 8: +15 us per product (26 - 28 against 23 - 26 ms for a solve of 128 products), / 2: no difference.  The
+    // two extra cross-stream event hops cost more than the floor they hide.  Removed.)
     double *xx = const_cast<double *>(x);
     const bool blk = blocked_usable(h);
     const double frac_if = blk ? h->blkA.frac_if : (double)h->splitA.n_interface / std::max(1, h->N2);
