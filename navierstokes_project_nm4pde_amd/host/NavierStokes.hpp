@@ -130,8 +130,9 @@ public:
       else assemble_time_step(time);
       solve_time_step();
       current_time = time;
-      // NavierStokes3D.cpp:725-726: `time == T - deltat` in floating point; compared to half a step here
-      if (dim == 3 && std::fabs(time - (T - deltat)) < 0.5 * deltat) compute_pressure_difference();
+      // NavierStokes3D.cpp:725-726, as written: an EXACT floating-point comparison of the accumulated time with T - deltat (true or false
+      // by the rounding of the additions; the reference's own run decides it the same way, so the mirror does not "repair" it)
+      if (dim == 3 && time == T - deltat) compute_pressure_difference();
       // NavierStokes3D.cpp:728-733 (forces only after t = 0.1); NavierStokes2D.cpp:737-741 (every step)
       std::vector<double> coefficients = {0.0, 0.0};
       if (dim == 2 || time > 0.1) {
