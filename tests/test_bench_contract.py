@@ -65,3 +65,14 @@ def test_committed_bench_line_carries_the_contract_fields():
 def test_bench_help_runs_without_a_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "--gpus" in r.stdout and "--steps" in r.stdout and "--warmup" in r.stdout
+
+
+def test_round_tools_parse():
+    """the measurement scripts the profiles were made with are at least valid bash / python (they run on the GPU box only)"""
+    import glob
+    import py_compile
+    for sh in glob.glob(os.path.join(ROOT, "tools", "*.sh")):
+        r = subprocess.run(["bash", "-n", sh], capture_output=True, text=True)
+        assert r.returncode == 0, (sh, r.stderr)
+    for py in glob.glob(os.path.join(ROOT, "tools", "*.py")):
+        py_compile.compile(py, doraise=True)
