@@ -54,7 +54,7 @@ else:
 BIG_STEPS, BIG_WARMUP, BIG_SPINUP = _BIG_SCHEDULE or (6, 1, 3)  # schedule of the strong_10M leg: the same on one GPU (committed base) and on N (short: at N = 2 a step of
                                              # this mesh still takes seconds, and the whole invocation has to stay within minutes)
 PMC_PROFILE = "profiles/r05_pmc_fetch_write_per_kernel.json"
-LAYOUT_PROFILE = "profiles/r04_layout_iterations.json"
+LAYOUT_PROFILE = "profiles/r05_layout_iterations.json"
 BIG_BASE_PROFILE = "profiles/r05_strong_10M_one_gpu.json"
 STEP_HISTORY = "profiles/r05_step_history.txt"
 NU, DT = 1e-3, 2e-4
